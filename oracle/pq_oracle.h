@@ -1,0 +1,154 @@
+/*
+ * pq_oracle.h — CPU oracle for the Parquet page-value decode path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a scalar, value-at-a-time C restatement of
+ * the decoding algorithm of hexbee-net/parquet-go (Go), used as the checker in
+ * tests/, in the smoke test and as the timed "port" CPU baseline of bench.py.
+ * Nothing in the shipped library links, loads or calls it.
+ *
+ * Parity pinning: every function below is checked against the reference's own
+ * known-answer vectors (the JSON files under tests/golden, transcribed from
+ * encoding/bitpacking32_test.go, encoding/bitpacking64_test.go,
+ * encoding/hybrid-decoder_test.go, encoding/hybrid-encoder_test.go,
+ * encoding/delta-binary-packed-decoder_test.go,
+ * encoding/delta-binary-packed-encoder_test.go, encoding/packed-array_test.go).
+ * The reference has no tests for types.DictDecoder, layout.decodePackedArray,
+ * the V1/V2 page section order, multi-block delta streams or multi-run hybrid
+ * decoding: for those the oracle follows the reference source line by line and
+ * its parity is UNPINNED by any reference fixture.  The Go toolchain is not
+ * available, so the reference itself was never executed.
+ */
+#ifndef PQ_ORACLE_H
+#define PQ_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Error classes of the reference (numbering is shared with include/pqdecode.h
+ * on purpose so tests can compare codes directly). */
+enum pqo_status {
+    PQO_OK = 0,
+    PQO_EOF = 1,                     /* io.EOF */
+    PQO_UNEXPECTED_EOF = 2,          /* io.ErrUnexpectedEOF */
+    PQO_EMPTY_BP_RUN = 3,            /* "rle: empty bit-packed run"     hybrid-decoder.go:123 */
+    PQO_EMPTY_RLE_RUN = 4,           /* "rle: empty RLE run"            hybrid-decoder.go:130 */
+    PQO_RLE_VALUE_TOO_LARGE = 5,     /* "rle: RLE run value is too large" hybrid-decoder.go:166 */
+    PQO_INT32_OUT_OF_RANGE = 6,      /* "int32 out of range"            helpers.go:36,54 */
+    PQO_VARINT_OVERFLOW = 7,         /* encoding/binary: varint overflows a 64-bit integer */
+    PQO_INVALID_BLOCK_SIZE = 8,      /* delta-binary-packed-decoder.go:34 */
+    PQO_INVALID_MINIBLOCK_COUNT = 9, /* delta-binary-packed-decoder.go:46 */
+    PQO_INVALID_MINIBLOCK_WIDTH = 10,/* delta-binary-packed-decoder.go:80 */
+    PQO_DICT_INVALID_WIDTH = 11,     /* types/dict.go:75 */
+    PQO_DICT_INVALID_INDEX = 12,     /* types/dict.go:104 (also the negative-key panic) */
+    PQO_NOT_INITIALIZED = 13,        /* "reader is not initialized"     hybrid-decoder.go:79 */
+    PQO_INVALID_STREAM = 14,         /* "invalid stream"                delta-binary-packed-decoder.go:154 */
+    PQO_PAGE_VALUES_FAILED = 15      /* "read values from page failed"  page-v1.go:104, page-v2.go:137 */
+};
+
+/* Stage of a data-page read at which an error surfaced (page-v1.go, page-v2.go). */
+enum pqo_stage {
+    PQO_STAGE_NONE = 0,
+    PQO_STAGE_REP_INIT = 1,
+    PQO_STAGE_DEF_INIT = 2,
+    PQO_STAGE_VALUES_INIT = 3,
+    PQO_STAGE_REP = 4,
+    PQO_STAGE_DEF = 5,
+    PQO_STAGE_VALUES = 6
+};
+
+enum pqo_value_kind {
+    PQO_VALUES_DICT = 1,    /* types.DictDecoder, elem_size bytes per dictionary entry */
+    PQO_VALUES_DELTA32 = 2, /* types.Int32DeltaBPDecoder */
+    PQO_VALUES_DELTA64 = 3  /* types.Int64DeltaBPDecoder */
+};
+
+/* ---- fixed-width bit packing (encoding/bitpacking32.go, bitpacking64.go) ---- */
+void pqo_unpack8_32(const uint8_t *data, int w, int32_t out[8]);
+void pqo_pack8_32(const int32_t in[8], int w, uint8_t *out);
+void pqo_unpack8_64(const uint8_t *data, int w, int64_t out[8]);
+void pqo_pack8_64(const int64_t in[8], int w, uint8_t *out);
+/* n_groups consecutive groups, value-at-a-time group calls like the Go table dispatch */
+void pqo_bitunpack32(const uint8_t *src, int w, size_t n_groups, int32_t *dst);
+void pqo_bitunpack64(const uint8_t *src, int w, size_t n_groups, int64_t *dst);
+
+/* ---- hybrid RLE / bit-packed (encoding/hybrid-decoder.go) ----
+ * length_prefixed: 1 = InitSize (u32 LE byte length first; no-op when w == 0),
+ *                  0 = Init on the whole slice.
+ * Pulls exactly n values with Next(); stops at the first error.
+ * consumed = bytes of src taken by the decoder's reader when it stopped
+ * (for the length-prefixed form: 4 + min(len, remaining) as InitSize slurps it). */
+int pqo_hybrid_decode(const uint8_t *src, size_t src_len, int w, int length_prefixed,
+                      uint32_t n, int32_t *dst, uint32_t *n_decoded, uint64_t *consumed);
+
+/* ---- dictionary-index pages (types/dict.go:61-117) ----
+ * src starts at the bit-width byte.  dict holds dict_len entries of elem_size bytes. */
+int pqo_dict_decode(const uint8_t *src, size_t src_len, const void *dict, uint32_t dict_len,
+                    uint32_t elem_size, uint32_t n, void *dst, uint32_t *n_decoded,
+                    uint64_t *consumed);
+
+/* ---- levels (layout/helpers.go:68-90, layout/chunk.go:78-124, encoding/packed-array.go) ----
+ * mode: 0 = ConstDecoder(0) (reads nothing), 1 = V1 (length-prefixed hybrid),
+ *       2 = V2 (raw hybrid over exactly src_len bytes; src_len == 0 leaves the
+ *           decoder uninitialised as page-v2.go:92-102 does).
+ * levels: n int32 (what Next() yields).  packed: PackedArray.data bytes
+ * (capacity >= (n/8+1)*bw), packed_len its length, tail[8]/tail_len the
+ * unflushed PackedArray.buf / bufPos. */
+int pqo_levels_decode(const uint8_t *src, size_t src_len, uint32_t max_level, int mode,
+                      uint32_t n, int32_t *levels, uint8_t *packed, uint64_t *packed_len,
+                      int32_t tail[8], uint32_t *tail_len, uint32_t *not_null,
+                      uint64_t *consumed);
+
+/* ---- DELTA_BINARY_PACKED (encoding/delta-binary-packed-decoder.go) ----
+ * Init + n pulls.  values_count = header's total value count (0 if the header failed).
+ * init_status = result of Init alone (DecodeValues is attempted only if it is OK). */
+int pqo_delta_decode32(const uint8_t *src, size_t src_len, uint32_t n, int32_t *dst,
+                       uint32_t *n_decoded, uint64_t *consumed, uint32_t *values_count,
+                       int *init_status);
+int pqo_delta_decode64(const uint8_t *src, size_t src_len, uint32_t n, int64_t *dst,
+                       uint32_t *n_decoded, uint64_t *consumed, uint32_t *values_count,
+                       int *init_status);
+
+/* ---- data pages (layout/page-v1.go:40-116, layout/page-v2.go:42-149) ---- */
+typedef struct pqo_page_in {
+    const uint8_t *src;      /* V1: decompressed block; V2: rep bytes, def bytes, values */
+    uint64_t src_len;
+    uint32_t version;        /* 1 or 2 */
+    uint32_t num_values;     /* header NumValues == len(values) handed to ReadValues */
+    uint32_t max_rep, max_def;
+    uint32_t rep_len, def_len; /* V2 only */
+    uint32_t value_kind;     /* enum pqo_value_kind */
+    uint32_t elem_size;      /* dictionary entry bytes (DICT) */
+    const void *dict;
+    uint32_t dict_len;
+} pqo_page_in;
+
+typedef struct pqo_page_out {
+    int32_t status;          /* enum pqo_status */
+    int32_t stage;           /* enum pqo_stage */
+    int32_t detail;          /* underlying status when status == PQO_PAGE_VALUES_FAILED */
+    uint32_t n;              /* ReadValues' n */
+    uint32_t not_null;
+    uint32_t values_decoded; /* count returned by DecodeValues */
+} pqo_page_out;
+
+/* rep/def: num_values int32 each; values: num_values entries of the value type. */
+void pqo_page_read(const pqo_page_in *in, int32_t *rep, int32_t *def, void *values,
+                   pqo_page_out *out);
+
+/* ---- encoders, used only to generate inputs the reference itself would produce
+ *      (encoding/hybrid-encoder.go, encoding/delta-binary-packed-encoder.go) ---- */
+int pqo_hybrid_encode(const int32_t *values, size_t n, int w, uint8_t *out, size_t cap,
+                      size_t *out_len);
+int pqo_delta_encode32(const int32_t *values, size_t n, int block_size, int miniblocks,
+                       uint8_t *out, size_t cap, size_t *out_len);
+int pqo_delta_encode64(const int64_t *values, size_t n, int block_size, int miniblocks,
+                       uint8_t *out, size_t cap, size_t *out_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQ_ORACLE_H */

@@ -1,0 +1,232 @@
+"""ctypes binding of the CPU oracle (oracle/libpqoracle.so).
+
+Test infrastructure only: imported by tests/, by __graft_entry__.smoke() and by
+the cpu_baseline leg of bench.py — never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(_ROOT, "oracle", "libpqoracle.so")
+
+# status codes (oracle/pq_oracle.h, enum pqo_status)
+OK, EOF, UNEXPECTED_EOF, EMPTY_BP_RUN, EMPTY_RLE_RUN, RLE_VALUE_TOO_LARGE = 0, 1, 2, 3, 4, 5
+INT32_OUT_OF_RANGE, VARINT_OVERFLOW, INVALID_BLOCK_SIZE, INVALID_MINIBLOCK_COUNT = 6, 7, 8, 9
+INVALID_MINIBLOCK_WIDTH, DICT_INVALID_WIDTH, DICT_INVALID_INDEX, NOT_INITIALIZED = 10, 11, 12, 13
+INVALID_STREAM, PAGE_VALUES_FAILED = 14, 15
+
+VALUES_DICT, VALUES_DELTA32, VALUES_DELTA64 = 1, 2, 3
+
+
+def build():
+    """Compile the oracle if the shared object is missing or stale."""
+    src = os.path.join(_ROOT, "oracle", "pq_oracle.c")
+    hdr = os.path.join(_ROOT, "oracle", "pq_oracle.h")
+    if (not os.path.exists(_SO)) or (
+            os.path.exists(src) and os.path.getmtime(_SO) < max(os.path.getmtime(src),
+                                                                os.path.getmtime(hdr))):
+        subprocess.check_call(["make", "-C", os.path.join(_ROOT, "oracle")])
+
+
+class PageIn(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_len", C.c_uint64), ("version", C.c_uint32),
+                ("num_values", C.c_uint32), ("max_rep", C.c_uint32), ("max_def", C.c_uint32),
+                ("rep_len", C.c_uint32), ("def_len", C.c_uint32), ("value_kind", C.c_uint32),
+                ("elem_size", C.c_uint32), ("dict", C.c_void_p), ("dict_len", C.c_uint32)]
+
+
+class PageOut(C.Structure):
+    _fields_ = [("status", C.c_int32), ("stage", C.c_int32), ("detail", C.c_int32),
+                ("n", C.c_uint32), ("not_null", C.c_uint32), ("values_decoded", C.c_uint32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.pqo_page_read.restype = None
+    return _lib
+
+
+def _u8(buf):
+    a = np.frombuffer(bytes(buf), dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.size == 0:
+        a = np.zeros(1, dtype=np.uint8)[:0]
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def unpack8_32(data, w):
+    d = _u8(list(data) + [0]) if len(data) == 0 else _u8(data)
+    out = np.zeros(8, dtype=np.int32)
+    lib().pqo_unpack8_32(_ptr(d), C.c_int(w), _ptr(out))
+    return out
+
+
+def unpack8_64(data, w):
+    d = _u8(list(data) + [0]) if len(data) == 0 else _u8(data)
+    out = np.zeros(8, dtype=np.int64)
+    lib().pqo_unpack8_64(_ptr(d), C.c_int(w), _ptr(out))
+    return out
+
+
+def pack8_32(values, w):
+    v = np.ascontiguousarray(values, dtype=np.int32)
+    out = np.zeros(max(w, 1), dtype=np.uint8)
+    lib().pqo_pack8_32(_ptr(v), C.c_int(w), _ptr(out))
+    return out[:w]
+
+
+def pack8_64(values, w):
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    out = np.zeros(max(w, 1), dtype=np.uint8)
+    lib().pqo_pack8_64(_ptr(v), C.c_int(w), _ptr(out))
+    return out[:w]
+
+
+def bitunpack32(src, w, n_groups):
+    s = _u8(src)
+    out = np.zeros(8 * n_groups, dtype=np.int32)
+    lib().pqo_bitunpack32(_ptr(s), C.c_int(w), C.c_size_t(n_groups), _ptr(out))
+    return out
+
+
+def bitunpack64(src, w, n_groups):
+    s = _u8(src)
+    out = np.zeros(8 * n_groups, dtype=np.int64)
+    lib().pqo_bitunpack64(_ptr(s), C.c_int(w), C.c_size_t(n_groups), _ptr(out))
+    return out
+
+
+def hybrid_decode(src, w, n, length_prefixed=False):
+    """-> (status, values[:n_decoded], consumed)"""
+    s = _u8(src)
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    nd, cons = C.c_uint32(0), C.c_uint64(0)
+    st = lib().pqo_hybrid_decode(_ptr(s), C.c_size_t(s.size), C.c_int(w),
+                                 C.c_int(int(length_prefixed)), C.c_uint32(n), _ptr(out),
+                                 C.byref(nd), C.byref(cons))
+    return st, out[:nd.value].copy(), cons.value
+
+
+def dict_decode(src, dictionary, n):
+    """dictionary: 1-D numpy array (int32/int64/float32/float64). -> (status, values, n_decoded, consumed)"""
+    s = _u8(src)
+    d = np.ascontiguousarray(dictionary)
+    out = np.zeros(max(n, 1), dtype=d.dtype)
+    nd, cons = C.c_uint32(0), C.c_uint64(0)
+    dptr = _ptr(d) if d.size else None
+    st = lib().pqo_dict_decode(_ptr(s), C.c_size_t(s.size), dptr, C.c_uint32(d.size),
+                               C.c_uint32(d.dtype.itemsize), C.c_uint32(n), _ptr(out),
+                               C.byref(nd), C.byref(cons))
+    return st, out[:n], nd.value, cons.value
+
+
+def levels_decode(src, max_level, n, mode):
+    """mode 0 const / 1 V1 length-prefixed / 2 V2 raw.
+    -> dict(status, levels, packed, tail, not_null, consumed)"""
+    s = _u8(src)
+    bw = int(max_level).bit_length() if max_level < 65536 else 16
+    levels = np.zeros(max(n, 1), dtype=np.int32)
+    packed = np.zeros((n // 8 + 2) * max(bw, 1), dtype=np.uint8)
+    plen, cons = C.c_uint64(0), C.c_uint64(0)
+    tail = np.zeros(8, dtype=np.int32)
+    tlen, nn = C.c_uint32(0), C.c_uint32(0)
+    st = lib().pqo_levels_decode(_ptr(s), C.c_size_t(s.size), C.c_uint32(max_level), C.c_int(mode),
+                                 C.c_uint32(n), _ptr(levels), _ptr(packed), C.byref(plen),
+                                 _ptr(tail), C.byref(tlen), C.byref(nn), C.byref(cons))
+    return dict(status=st, levels=levels[:n], packed=packed[:plen.value].copy(),
+                tail=tail[:tlen.value].copy(), not_null=nn.value, consumed=cons.value)
+
+
+def _delta(fn, dtype, src, n):
+    s = _u8(src)
+    out = np.zeros(max(n, 1), dtype=dtype)
+    nd, cons, vc, ist = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0), C.c_int(0)
+    st = fn(_ptr(s), C.c_size_t(s.size), C.c_uint32(n), _ptr(out), C.byref(nd), C.byref(cons),
+            C.byref(vc), C.byref(ist))
+    return dict(status=st, values=out[:nd.value].copy(), n_decoded=nd.value,
+                consumed=cons.value, values_count=vc.value, init_status=ist.value)
+
+
+def delta_decode32(src, n):
+    return _delta(lib().pqo_delta_decode32, np.int32, src, n)
+
+
+def delta_decode64(src, n):
+    return _delta(lib().pqo_delta_decode64, np.int64, src, n)
+
+
+def hybrid_encode(values, w):
+    v = np.ascontiguousarray(values, dtype=np.int32)
+    cap = v.size * 5 + v.size // 8 + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    ol = C.c_size_t(0)
+    vp = _ptr(v) if v.size else None
+    rc = lib().pqo_hybrid_encode(vp, C.c_size_t(v.size), C.c_int(w), _ptr(out), C.c_size_t(cap),
+                                 C.byref(ol))
+    assert rc == 0, rc
+    return out[:ol.value].copy()
+
+
+def _delta_encode(fn, dtype, values, block, miniblocks):
+    v = np.ascontiguousarray(values, dtype=dtype)
+    cap = v.size * 10 + (v.size // 128 + 2) * (miniblocks + 16) + block * 9 + 128
+    out = np.zeros(cap, dtype=np.uint8)
+    ol = C.c_size_t(0)
+    vp = _ptr(v) if v.size else None
+    rc = fn(vp, C.c_size_t(v.size), C.c_int(block), C.c_int(miniblocks), _ptr(out),
+            C.c_size_t(cap), C.byref(ol))
+    return rc, out[:ol.value].copy()
+
+
+def delta_encode32(values, block=128, miniblocks=4):
+    return _delta_encode(lib().pqo_delta_encode32, np.int32, values, block, miniblocks)
+
+
+def delta_encode64(values, block=128, miniblocks=4):
+    return _delta_encode(lib().pqo_delta_encode64, np.int64, values, block, miniblocks)
+
+
+def page_read(src, version, num_values, max_rep, max_def, value_kind, dictionary=None,
+              rep_len=0, def_len=0, value_dtype=None):
+    """-> dict(status, stage, detail, n, not_null, values_decoded, rep, def_, values)"""
+    s = _u8(src)
+    pin = PageIn()
+    pin.src = s.ctypes.data if s.size else None
+    pin.src_len = s.size
+    pin.version = version
+    pin.num_values = num_values
+    pin.max_rep, pin.max_def = max_rep, max_def
+    pin.rep_len, pin.def_len = rep_len, def_len
+    pin.value_kind = value_kind
+    d = None
+    if value_kind == VALUES_DICT:
+        d = np.ascontiguousarray(dictionary)
+        pin.dict = d.ctypes.data if d.size else None
+        pin.dict_len = d.size
+        pin.elem_size = d.dtype.itemsize
+        vdt = d.dtype
+    else:
+        vdt = np.dtype(np.int32 if value_kind == VALUES_DELTA32 else np.int64)
+    if value_dtype is not None:
+        vdt = np.dtype(value_dtype)
+    rep = np.zeros(max(num_values, 1), dtype=np.int32)
+    deff = np.zeros(max(num_values, 1), dtype=np.int32)
+    vals = np.zeros(max(num_values, 1), dtype=vdt)
+    po = PageOut()
+    lib().pqo_page_read(C.byref(pin), _ptr(rep), _ptr(deff), _ptr(vals), C.byref(po))
+    return dict(status=po.status, stage=po.stage, detail=po.detail, n=po.n, not_null=po.not_null,
+                values_decoded=po.values_decoded, rep=rep[:num_values], def_=deff[:num_values],
+                values=vals[:num_values])
