@@ -1,0 +1,195 @@
+/*
+ * pqdecode.h — C ABI of the MI355X (gfx950) Parquet page-value decoder.
+ *
+ * Drop-in boundary for the decode hot path of hexbee-net/parquet-go.  The
+ * reference has no FFI of its own; each entry point below names the Go
+ * interface or function whose body a cgo shim replaces with a call to it
+ * (paths are relative to the reference root).  Everything is plain pointers
+ * and sizes; the caller owns every buffer; the library keeps no caller pointer
+ * after a call returns unless stated.  No function throws or aborts: every
+ * failure is an integer status.
+ *
+ * Two flavours of each operation:
+ *   *_dev / pq_plan_*  device pointers in and out, asynchronous on the
+ *                      context's HIP stream (the device-resident path);
+ *   plain names        host pointers; the call stages H2D, decodes, copies
+ *                      D2H and synchronises before returning.
+ *
+ * Threading: a pq_ctx (and the plans made from it) may be used by one thread at
+ * a time; create one context per calling thread / goroutine-locked OS thread.
+ */
+#ifndef PQDECODE_H
+#define PQDECODE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ---------------------------------------------------------
+ * 1..15 are the reference's error classes; >= 100 are the library's own. */
+#define PQ_OK 0
+#define PQ_EOF 1                     /* io.EOF */
+#define PQ_UNEXPECTED_EOF 2          /* io.ErrUnexpectedEOF */
+#define PQ_EMPTY_BP_RUN 3            /* encoding/hybrid-decoder.go:123 */
+#define PQ_EMPTY_RLE_RUN 4           /* encoding/hybrid-decoder.go:130 */
+#define PQ_RLE_VALUE_TOO_LARGE 5     /* encoding/hybrid-decoder.go:166 */
+#define PQ_INT32_OUT_OF_RANGE 6      /* encoding/helpers.go:36,54 */
+#define PQ_VARINT_OVERFLOW 7         /* Go encoding/binary varint overflow */
+#define PQ_INVALID_BLOCK_SIZE 8      /* encoding/delta-binary-packed-decoder.go:34 */
+#define PQ_INVALID_MINIBLOCK_COUNT 9 /* encoding/delta-binary-packed-decoder.go:46 */
+#define PQ_INVALID_MINIBLOCK_WIDTH 10/* encoding/delta-binary-packed-decoder.go:80 */
+#define PQ_DICT_INVALID_WIDTH 11     /* types/dict.go:75 */
+#define PQ_DICT_INVALID_INDEX 12     /* types/dict.go:104 (and the negative-key panic) */
+#define PQ_NOT_INITIALIZED 13        /* encoding/hybrid-decoder.go:79 */
+#define PQ_INVALID_STREAM 14         /* encoding/delta-binary-packed-decoder.go:154 */
+#define PQ_PAGE_VALUES_FAILED 15     /* layout/page-v1.go:104, layout/page-v2.go:137 */
+
+#define PQ_ERR_BAD_ARGUMENT 100
+#define PQ_ERR_HIP 101               /* a HIP runtime call failed; see pq_last_error */
+#define PQ_ERR_NO_DEVICE 102
+#define PQ_ERR_OUT_OF_RANGE 103      /* a descriptor points outside the buffers given */
+
+/* stage of a data-page read at which `status` surfaced (pq_page_result.stage) */
+#define PQ_STAGE_NONE 0
+#define PQ_STAGE_REP_INIT 1
+#define PQ_STAGE_DEF_INIT 2
+#define PQ_STAGE_VALUES_INIT 3
+#define PQ_STAGE_REP 4
+#define PQ_STAGE_DEF 5
+#define PQ_STAGE_VALUES 6
+
+/* ---- context ------------------------------------------------------------- */
+typedef struct pq_ctx pq_ctx;
+
+/* hip_stream: a hipStream_t to launch on (e.g. the caller's stream), or NULL to
+ * let the library create its own non-blocking stream on `device`. */
+int pq_ctx_create(int device, void *hip_stream, pq_ctx **out);
+void pq_ctx_destroy(pq_ctx *ctx);
+int pq_ctx_synchronize(pq_ctx *ctx);
+const char *pq_status_string(int status);
+const char *pq_last_error(pq_ctx *ctx); /* text of the last HIP failure on ctx */
+int pq_version(void);
+
+/* ---- fixed-width bit-unpack ----------------------------------------------
+ * Replaces the unpack8int32_w / unpack8int64_w table calls
+ * (encoding/bitpacking32.go:10-44, encoding/bitpacking64.go:10-76) over
+ * n_groups consecutive groups of 8 values: group g is the w bytes at
+ * src + g*w, value k of it = bits [k*w,(k+1)*w) of that little-endian group.
+ * 0 <= w <= 32 (int32) / 64 (int64); src_len >= n_groups*w. */
+int pq_bitunpack32_dev(pq_ctx *ctx, const void *d_src, size_t src_len, int w, size_t n_groups,
+                       int32_t *d_dst);
+int pq_bitunpack64_dev(pq_ctx *ctx, const void *d_src, size_t src_len, int w, size_t n_groups,
+                       int64_t *d_dst);
+int pq_bitunpack32(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, size_t n_groups,
+                   int32_t *dst);
+int pq_bitunpack64(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, size_t n_groups,
+                   int64_t *dst);
+
+/* ---- page descriptors ----------------------------------------------------
+ * One descriptor = one unit of independent work (one encoded stream or one
+ * whole data page).  Offsets are BYTES into the buffers handed to
+ * pq_plan_run / pq_decode_pages. */
+#define PQ_KIND_HYBRID 1   /* encoding.HybridDecoder: Init/InitSize + n x Next()
+                              (encoding/hybrid-decoder.go:42-109) -> int32 */
+#define PQ_KIND_DICT 2     /* types.DictDecoder.Init + DecodeValues (types/dict.go:66-117):
+                              src starts at the bit-width byte -> elem_size-byte values */
+#define PQ_KIND_LEVELS 3   /* layout.decodePackedArray over a level decoder
+                              (layout/helpers.go:68-90, layout/chunk.go:78-124) -> int32
+                              levels + not_null */
+#define PQ_KIND_DELTA32 4  /* types.Int32DeltaBPDecoder Init + DecodeValues
+                              (types/int32.go:103-123, encoding/delta-binary-packed-decoder.go:174-246) */
+#define PQ_KIND_DELTA64 5  /* types.Int64DeltaBPDecoder (types/int64.go:103-123,
+                              encoding/delta-binary-packed-decoder.go:250-322) */
+#define PQ_KIND_PAGE_V1 6  /* dataPageReaderV1.read + ReadValues (layout/page-v1.go:40-116) */
+#define PQ_KIND_PAGE_V2 7  /* dataPageReaderV2.read + ReadValues (layout/page-v2.go:42-149) */
+
+#define PQ_FLAG_LENGTH_PREFIXED 1u /* HYBRID/LEVELS: InitSize (u32 LE length first) */
+#define PQ_FLAG_LEVELS_CONST 2u    /* LEVELS: ConstDecoder(0) (layout/chunk.go:111-124) */
+#define PQ_FLAG_NO_INIT 4u         /* HYBRID/LEVELS: decoder never initialised
+                                      (zero-length V2 level section, layout/page-v2.go:92-102) */
+
+typedef struct pq_page_desc {
+    uint32_t kind;        /* PQ_KIND_* */
+    uint32_t flags;       /* PQ_FLAG_* */
+    uint64_t src_off;     /* first byte of this unit in the source buffer */
+    uint64_t src_len;     /* bytes available to it */
+    uint64_t dst_off;     /* byte offset of its value output in the values buffer */
+    uint64_t rep_off;     /* byte offset of its int32 rep-level output (levels buffer) */
+    uint64_t def_off;     /* byte offset of its int32 def-level output (levels buffer);
+                             PQ_KIND_LEVELS writes its single stream here */
+    uint64_t dict_off;    /* byte offset of the dictionary in the dictionary buffer */
+    uint32_t n_values;    /* values to pull; for pages: header NumValues (level slots) */
+    uint32_t bit_width;   /* HYBRID: w (0..32) */
+    uint32_t max_rep;     /* pages: column max repetition level */
+    uint32_t max_def;     /* pages: max definition level; LEVELS: the stream's max level */
+    uint32_t rep_len;     /* PAGE_V2: RepetitionLevelsByteLength */
+    uint32_t def_len;     /* PAGE_V2: DefinitionLevelsByteLength */
+    uint32_t value_kind;  /* pages: PQ_KIND_DICT, PQ_KIND_DELTA32 or PQ_KIND_DELTA64 */
+    uint32_t elem_size;   /* DICT: bytes per dictionary entry (4 or 8) */
+    uint32_t dict_len;    /* DICT: number of dictionary entries */
+    uint32_t reserved;
+} pq_page_desc;
+
+typedef struct pq_page_result {
+    int32_t status;      /* PQ_OK or the reference's error class */
+    int32_t stage;       /* PQ_STAGE_*: pages only */
+    int32_t detail;      /* underlying status when status == PQ_PAGE_VALUES_FAILED */
+    uint32_t n_decoded;  /* values written (what DecodeValues returns); levels: slots */
+    uint32_t not_null;   /* LEVELS and pages: #{def == max_def} */
+    uint32_t n_levels;   /* pages: ReadValues' n (0 on any error) */
+    uint64_t consumed;   /* bytes of src the reference's reader would have consumed
+                            (defined when status == PQ_OK) */
+} pq_page_result;
+
+/* ---- batched, device-resident decode --------------------------------------
+ * A plan is an uploaded descriptor table plus a device-side result table.
+ * pq_plan_run launches the decode kernels for every descriptor, asynchronously
+ * on the context's stream, and touches no host memory: this is the path the
+ * reference's readPageData loop (file-reader.go:268-302) maps to when all pages
+ * of a column chunk are handed over at once.  Buffers are device pointers;
+ * *_bytes are their sizes (used only for range checks). */
+typedef struct pq_plan pq_plan;
+
+int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_plan **out);
+int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_values,
+                size_t values_bytes, void *d_levels, size_t levels_bytes, const void *d_dict,
+                size_t dict_bytes);
+/* Waits for the stream and copies the per-page results to host memory. */
+int pq_plan_results(pq_plan *plan, pq_page_result *results);
+void pq_plan_destroy(pq_plan *plan);
+
+/* ---- batched decode from host memory ---------------------------------------
+ * Same as create + run + results with host buffers: copies src and dict to the
+ * device, decodes, copies values/levels back.  Any of values/levels/dict may be
+ * NULL when no descriptor uses it. */
+int pq_decode_pages(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, const void *src,
+                    size_t src_bytes, void *values, size_t values_bytes, void *levels,
+                    size_t levels_bytes, const void *dict, size_t dict_bytes,
+                    pq_page_result *results);
+
+/* ---- single-stream conveniences (host memory), one call per reference call --
+ * hybrid:  HybridDecoder.Init/InitSize + n x Next()   (encoding/hybrid-decoder.go:42-109)
+ * dict:    DictDecoder.Init + DecodeValues(dest[:n])  (types/dict.go:66-117)
+ * levels:  decodePackedArray(d, n)                    (layout/helpers.go:68-90);
+ *          mode 0 = ConstDecoder, 1 = V1 length-prefixed, 2 = V2 raw
+ * delta:   Int32/Int64DeltaBPDecoder.Init + DecodeValues(dest[:n])
+ * Each returns the status; n_decoded / not_null / consumed may be NULL. */
+int pq_hybrid_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, int length_prefixed,
+                     uint32_t n, int32_t *dst, uint32_t *n_decoded, uint64_t *consumed);
+int pq_dict_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, const void *dict,
+                   uint32_t dict_len, uint32_t elem_size, uint32_t n, void *dst,
+                   uint32_t *n_decoded, uint64_t *consumed);
+int pq_levels_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t max_level, int mode,
+                     uint32_t n, int32_t *levels, uint32_t *not_null, uint64_t *consumed);
+int pq_delta_decode32(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n, int32_t *dst,
+                      uint32_t *n_decoded, uint64_t *consumed);
+int pq_delta_decode64(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n, int64_t *dst,
+                      uint32_t *n_decoded, uint64_t *consumed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQDECODE_H */

@@ -1,0 +1,273 @@
+"""ctypes binding of libpqdecode.so (the C ABI declared in include/pqdecode.h).
+
+This is plumbing for tests and the benchmark: every decode goes through the
+shared library's gfx950 kernels.  There is no Python or CPU decode path here; if
+the library is missing or no HIP device is present the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libpqdecode.so")
+
+# ---- status codes (include/pqdecode.h) ----
+OK, EOF, UNEXPECTED_EOF, EMPTY_BP_RUN, EMPTY_RLE_RUN, RLE_VALUE_TOO_LARGE = 0, 1, 2, 3, 4, 5
+INT32_OUT_OF_RANGE, VARINT_OVERFLOW, INVALID_BLOCK_SIZE, INVALID_MINIBLOCK_COUNT = 6, 7, 8, 9
+INVALID_MINIBLOCK_WIDTH, DICT_INVALID_WIDTH, DICT_INVALID_INDEX, NOT_INITIALIZED = 10, 11, 12, 13
+INVALID_STREAM, PAGE_VALUES_FAILED = 14, 15
+ERR_BAD_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_OUT_OF_RANGE = 100, 101, 102, 103
+
+KIND_HYBRID, KIND_DICT, KIND_LEVELS, KIND_DELTA32, KIND_DELTA64, KIND_PAGE_V1, KIND_PAGE_V2 = range(1, 8)
+FLAG_LENGTH_PREFIXED, FLAG_LEVELS_CONST, FLAG_NO_INIT = 1, 2, 4
+
+STAGE_NONE, STAGE_REP_INIT, STAGE_DEF_INIT, STAGE_VALUES_INIT, STAGE_REP, STAGE_DEF, STAGE_VALUES = range(7)
+
+EXPORTS = [
+    "pq_ctx_create", "pq_ctx_destroy", "pq_ctx_synchronize", "pq_status_string", "pq_last_error",
+    "pq_version", "pq_bitunpack32_dev", "pq_bitunpack64_dev", "pq_bitunpack32", "pq_bitunpack64",
+    "pq_plan_create", "pq_plan_run", "pq_plan_results", "pq_plan_destroy", "pq_decode_pages",
+    "pq_hybrid_decode", "pq_dict_decode", "pq_levels_decode", "pq_delta_decode32",
+    "pq_delta_decode64",
+]
+
+
+class PageDesc(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("flags", C.c_uint32), ("src_off", C.c_uint64),
+                ("src_len", C.c_uint64), ("dst_off", C.c_uint64), ("rep_off", C.c_uint64),
+                ("def_off", C.c_uint64), ("dict_off", C.c_uint64), ("n_values", C.c_uint32),
+                ("bit_width", C.c_uint32), ("max_rep", C.c_uint32), ("max_def", C.c_uint32),
+                ("rep_len", C.c_uint32), ("def_len", C.c_uint32), ("value_kind", C.c_uint32),
+                ("elem_size", C.c_uint32), ("dict_len", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class PageResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("stage", C.c_int32), ("detail", C.c_int32),
+                ("n_decoded", C.c_uint32), ("not_null", C.c_uint32), ("n_levels", C.c_uint32),
+                ("consumed", C.c_uint64)]
+
+
+DESC_DTYPE = np.dtype([("kind", "<u4"), ("flags", "<u4"), ("src_off", "<u8"), ("src_len", "<u8"),
+                       ("dst_off", "<u8"), ("rep_off", "<u8"), ("def_off", "<u8"),
+                       ("dict_off", "<u8"), ("n_values", "<u4"), ("bit_width", "<u4"),
+                       ("max_rep", "<u4"), ("max_def", "<u4"), ("rep_len", "<u4"),
+                       ("def_len", "<u4"), ("value_kind", "<u4"), ("elem_size", "<u4"),
+                       ("dict_len", "<u4"), ("reserved", "<u4")])
+RESULT_DTYPE = np.dtype([("status", "<i4"), ("stage", "<i4"), ("detail", "<i4"),
+                         ("n_decoded", "<u4"), ("not_null", "<u4"), ("n_levels", "<u4"),
+                         ("consumed", "<u8")])
+assert DESC_DTYPE.itemsize == C.sizeof(PageDesc) == 96
+assert RESULT_DTYPE.itemsize == C.sizeof(PageResult) == 32
+
+_lib = None
+
+
+def load():
+    """dlopen the library (does not touch the GPU)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libpqdecode.so is not built: run `make -C parquet-go_amd/csrc` "
+                "(or __graft_entry__.build()); there is no fallback decode path")
+        lib = C.CDLL(LIB_PATH)
+        lib.pq_status_string.restype = C.c_char_p
+        lib.pq_last_error.restype = C.c_char_p
+        lib.pq_last_error.argtypes = [C.c_void_p]
+        lib.pq_ctx_destroy.restype = None
+        lib.pq_ctx_destroy.argtypes = [C.c_void_p]
+        lib.pq_plan_destroy.restype = None
+        lib.pq_plan_destroy.argtypes = [C.c_void_p]
+        lib.pq_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        lib.pq_ctx_synchronize.argtypes = [C.c_void_p]
+        lib.pq_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        lib.pq_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        lib.pq_plan_results.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pq_decode_pages.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_size_t, C.c_void_p]
+        for name in ("pq_bitunpack32_dev", "pq_bitunpack64_dev", "pq_bitunpack32", "pq_bitunpack64"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t,
+                                           C.c_void_p]
+        lib.pq_hybrid_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                         C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_uint64)]
+        lib.pq_dict_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
+                                       C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32),
+                                       C.POINTER(C.c_uint64)]
+        lib.pq_levels_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int,
+                                         C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_uint64)]
+        for name in ("pq_delta_decode32", "pq_delta_decode64"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
+                                           C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        _lib = lib
+    return _lib
+
+
+def status_string(code):
+    return load().pq_status_string(int(code)).decode()
+
+
+class PqError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        super().__init__("pqdecode: %s (%d) %s" % (status_string(code), code, detail))
+
+
+def _np_u8(buf):
+    if isinstance(buf, np.ndarray):
+        a = np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
+    else:
+        a = np.frombuffer(bytes(buf), dtype=np.uint8)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data if (a is not None and a.size) else None
+
+
+class Context:
+    """A pq_ctx: one device + one HIP stream."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = load()
+        h = C.c_void_p()
+        st = self._lib.pq_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if st != OK:
+            raise PqError(st, "(pq_ctx_create)")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._lib.pq_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st, what=""):
+        if st >= ERR_BAD_ARGUMENT:
+            raise PqError(st, "%s %s" % (what, self._lib.pq_last_error(self._h).decode()))
+        return st
+
+    def synchronize(self):
+        self._check(self._lib.pq_ctx_synchronize(self._h))
+
+    # ---- host-memory entry points (numpy in / numpy out) ----
+    def bitunpack(self, src, w, n_groups, bits=32):
+        s = _np_u8(src)
+        out = np.empty(8 * n_groups, dtype=np.int32 if bits == 32 else np.int64)
+        fn = self._lib.pq_bitunpack32 if bits == 32 else self._lib.pq_bitunpack64
+        self._check(fn(self._h, _ptr(s), s.size, int(w), int(n_groups), _ptr(out)), "bitunpack")
+        return out
+
+    def hybrid_decode(self, src, w, n, length_prefixed=False):
+        s = _np_u8(src)
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        nd, cons = C.c_uint32(0), C.c_uint64(0)
+        st = self._check(self._lib.pq_hybrid_decode(self._h, _ptr(s), s.size, int(w),
+                                                    int(bool(length_prefixed)), int(n), _ptr(out),
+                                                    C.byref(nd), C.byref(cons)), "hybrid")
+        return st, out[:nd.value].copy(), cons.value
+
+    def dict_decode(self, src, dictionary, n):
+        s = _np_u8(src)
+        d = np.ascontiguousarray(dictionary)
+        out = np.zeros(max(n, 1), dtype=d.dtype)
+        nd, cons = C.c_uint32(0), C.c_uint64(0)
+        st = self._check(self._lib.pq_dict_decode(self._h, _ptr(s), s.size, _ptr(d), d.size,
+                                                  d.dtype.itemsize, int(n), _ptr(out), C.byref(nd),
+                                                  C.byref(cons)), "dict")
+        return st, out[:n], nd.value, cons.value
+
+    def levels_decode(self, src, max_level, n, mode):
+        s = _np_u8(src)
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        nn, cons = C.c_uint32(0), C.c_uint64(0)
+        st = self._check(self._lib.pq_levels_decode(self._h, _ptr(s), s.size, int(max_level),
+                                                    int(mode), int(n), _ptr(out), C.byref(nn),
+                                                    C.byref(cons)), "levels")
+        return dict(status=st, levels=out[:n], not_null=nn.value, consumed=cons.value)
+
+    def delta_decode(self, src, n, bits=64):
+        s = _np_u8(src)
+        out = np.zeros(max(n, 1), dtype=np.int32 if bits == 32 else np.int64)
+        nd, cons = C.c_uint32(0), C.c_uint64(0)
+        fn = self._lib.pq_delta_decode32 if bits == 32 else self._lib.pq_delta_decode64
+        st = self._check(fn(self._h, _ptr(s), s.size, int(n), _ptr(out), C.byref(nd),
+                            C.byref(cons)), "delta")
+        return dict(status=st, values=out[:nd.value].copy(), n_decoded=nd.value,
+                    consumed=cons.value)
+
+    def decode_pages(self, descs, src, values_bytes=0, levels_bytes=0, dictionary=None):
+        """descs: numpy array of DESC_DTYPE.  Returns (results, values_u8, levels_i32)."""
+        descs = np.ascontiguousarray(descs, dtype=DESC_DTYPE)
+        s = _np_u8(src)
+        values = np.zeros(values_bytes, dtype=np.uint8)
+        levels = np.zeros(levels_bytes // 4, dtype=np.int32)
+        d = _np_u8(dictionary) if dictionary is not None else np.zeros(0, np.uint8)
+        results = np.zeros(descs.size, dtype=RESULT_DTYPE)
+        st = self._lib.pq_decode_pages(self._h, _ptr(descs), descs.size, _ptr(s), s.size,
+                                       _ptr(values), values.size, _ptr(levels), levels.size * 4,
+                                       _ptr(d), d.size, _ptr(results))
+        if st != OK:
+            raise PqError(st, self._lib.pq_last_error(self._h).decode())
+        return results, values, levels
+
+    # ---- device-resident entry points (raw device pointers) ----
+    def bitunpack_dev(self, d_src, src_len, w, n_groups, d_dst, bits=32):
+        fn = self._lib.pq_bitunpack32_dev if bits == 32 else self._lib.pq_bitunpack64_dev
+        st = fn(self._h, C.c_void_p(d_src), int(src_len), int(w), int(n_groups), C.c_void_p(d_dst))
+        if st != OK:
+            raise PqError(st, self._lib.pq_last_error(self._h).decode())
+
+    def plan(self, descs):
+        return Plan(self, descs)
+
+
+class Plan:
+    """A pq_plan: uploaded descriptor table; run() only launches kernels."""
+
+    def __init__(self, ctx, descs):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        descs = np.ascontiguousarray(descs, dtype=DESC_DTYPE)
+        self.n = descs.size
+        h = C.c_void_p()
+        st = self._lib.pq_plan_create(ctx._h, _ptr(descs), descs.size, C.byref(h))
+        if st != OK:
+            raise PqError(st, "(pq_plan_create) " + self._lib.pq_last_error(ctx._h).decode())
+        self._h = h
+
+    def run(self, d_src, src_bytes, d_values=0, values_bytes=0, d_levels=0, levels_bytes=0,
+            d_dict=0, dict_bytes=0):
+        st = self._lib.pq_plan_run(self._h, C.c_void_p(d_src), int(src_bytes),
+                                   C.c_void_p(d_values) if d_values else None, int(values_bytes),
+                                   C.c_void_p(d_levels) if d_levels else None, int(levels_bytes),
+                                   C.c_void_p(d_dict) if d_dict else None, int(dict_bytes))
+        if st != OK:
+            raise PqError(st, "(pq_plan_run) " + self._lib.pq_last_error(self._ctx._h).decode())
+
+    def results(self):
+        out = np.zeros(self.n, dtype=RESULT_DTYPE)
+        st = self._lib.pq_plan_results(self._h, _ptr(out))
+        if st != OK:
+            raise PqError(st, "(pq_plan_results) " + self._lib.pq_last_error(self._ctx._h).decode())
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.pq_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,523 @@
+// capi.cpp — the C ABI of include/pqdecode.h: contexts, plans, staging, launches.
+//
+// Host-side only; all decoding happens in the gfx950 kernels of bitunpack.hip and
+// pages.hip.  There is no CPU decode path in this library: without a HIP device
+// every entry point fails with PQ_ERR_NO_DEVICE / PQ_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pq_launch.hpp"
+#include "pqdecode.h"
+
+struct pq_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+    // grow-only device staging used by the host-pointer entry points
+    void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_cap[4] = {0, 0, 0, 0};
+};
+
+struct pq_plan {
+    pq_ctx *ctx = nullptr;
+    size_t n = 0;
+    pq_page_desc *d_descs = nullptr;
+    uint32_t *d_ids = nullptr;
+    pq_page_result *d_results = nullptr;
+    // descriptor ids grouped by kernel: [stream | delta32 | delta64 | data pages]
+    uint32_t count[4] = {0, 0, 0, 0};
+    uint32_t first[4] = {0, 0, 0, 0};
+    uint64_t src_need = 0, values_need = 0, levels_need = 0, dict_need = 0;
+    uint32_t dict_lds_bytes = 0;
+    bool has_delta = false;
+};
+
+namespace {
+
+bool hip_ok(pq_ctx *ctx, hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    if (ctx) ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+
+#define PQ_HIP(ctx, call)                                  \
+    do {                                                   \
+        if (!hip_ok((ctx), (call), #call)) return PQ_ERR_HIP; \
+    } while (0)
+
+int group_of(uint32_t kind)
+{
+    switch (kind) {
+    case PQ_KIND_HYBRID:
+    case PQ_KIND_DICT:
+    case PQ_KIND_LEVELS: return 0;
+    case PQ_KIND_DELTA32: return 1;
+    case PQ_KIND_DELTA64: return 2;
+    case PQ_KIND_PAGE_V1:
+    case PQ_KIND_PAGE_V2: return 3;
+    default: return -1;
+    }
+}
+
+// Bytes per output value of a descriptor (0 = it writes no value output).
+uint32_t value_size(const pq_page_desc &d)
+{
+    uint32_t k = d.kind;
+    if (k == PQ_KIND_PAGE_V1 || k == PQ_KIND_PAGE_V2) k = d.value_kind;
+    switch (k) {
+    case PQ_KIND_HYBRID: return 4;
+    case PQ_KIND_DICT: return d.elem_size;
+    case PQ_KIND_DELTA32: return 4;
+    case PQ_KIND_DELTA64: return 8;
+    default: return 0;
+    }
+}
+
+int validate(const pq_page_desc &d)
+{
+    if (group_of(d.kind) < 0) return PQ_ERR_BAD_ARGUMENT;
+    if (d.n_values > 0x7fffffffu) return PQ_ERR_BAD_ARGUMENT; // counts are int32 in the reference
+    if (d.src_len > 0x7fffffffffffull) return PQ_ERR_BAD_ARGUMENT;
+    const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
+    if (page && d.value_kind != PQ_KIND_DICT && d.value_kind != PQ_KIND_DELTA32 &&
+        d.value_kind != PQ_KIND_DELTA64)
+        return PQ_ERR_BAD_ARGUMENT;
+    const bool dict = d.kind == PQ_KIND_DICT || (page && d.value_kind == PQ_KIND_DICT);
+    if (dict) {
+        if (d.elem_size != 4 && d.elem_size != 8) return PQ_ERR_BAD_ARGUMENT;
+        if (d.dict_off % d.elem_size) return PQ_ERR_BAD_ARGUMENT;
+        if (d.dict_len > 0x7fffffffu) return PQ_ERR_BAD_ARGUMENT;
+    }
+    // NewHybridDecoder indexes a 33-entry table with the width (hybrid-decoder.go:34)
+    if (d.kind == PQ_KIND_HYBRID && d.bit_width > 32) return PQ_ERR_BAD_ARGUMENT;
+    if (d.max_rep > 0xffffu || d.max_def > 0xffffu) return PQ_ERR_BAD_ARGUMENT; // levels are uint16
+    const uint32_t vs = value_size(d);
+    if (vs && d.dst_off % vs) return PQ_ERR_BAD_ARGUMENT;
+    if ((page || d.kind == PQ_KIND_LEVELS) && ((d.rep_off | d.def_off) & 3u)) return PQ_ERR_BAD_ARGUMENT;
+    return PQ_OK;
+}
+
+int ensure_stage(pq_ctx *ctx, int slot, size_t bytes)
+{
+    if (bytes <= ctx->stage_cap[slot]) return PQ_OK;
+    if (ctx->stage[slot]) {
+        PQ_HIP(ctx, hipFree(ctx->stage[slot]));
+        ctx->stage[slot] = nullptr;
+        ctx->stage_cap[slot] = 0;
+    }
+    const size_t cap = std::max<size_t>(bytes + bytes / 4, 1u << 20);
+    PQ_HIP(ctx, hipMalloc(&ctx->stage[slot], cap));
+    ctx->stage_cap[slot] = cap;
+    return PQ_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pq_version(void) { return 100; }
+
+const char *pq_status_string(int s)
+{
+    switch (s) {
+    case PQ_OK: return "ok";
+    case PQ_EOF: return "EOF";
+    case PQ_UNEXPECTED_EOF: return "unexpected EOF";
+    case PQ_EMPTY_BP_RUN: return "rle: empty bit-packed run";
+    case PQ_EMPTY_RLE_RUN: return "rle: empty RLE run";
+    case PQ_RLE_VALUE_TOO_LARGE: return "rle: RLE run value is too large";
+    case PQ_INT32_OUT_OF_RANGE: return "int32 out of range";
+    case PQ_VARINT_OVERFLOW: return "binary: varint overflows a 64-bit integer";
+    case PQ_INVALID_BLOCK_SIZE: return "invalid block size";
+    case PQ_INVALID_MINIBLOCK_COUNT: return "invalid miniblock count";
+    case PQ_INVALID_MINIBLOCK_WIDTH: return "invalid miniblock bit-width";
+    case PQ_DICT_INVALID_WIDTH: return "invalid bit-width";
+    case PQ_DICT_INVALID_INDEX: return "invalid index";
+    case PQ_NOT_INITIALIZED: return "reader is not initialized";
+    case PQ_INVALID_STREAM: return "invalid stream";
+    case PQ_PAGE_VALUES_FAILED: return "read values from page failed";
+    case PQ_ERR_BAD_ARGUMENT: return "bad argument";
+    case PQ_ERR_HIP: return "HIP runtime error";
+    case PQ_ERR_NO_DEVICE: return "no HIP device";
+    case PQ_ERR_OUT_OF_RANGE: return "descriptor outside the given buffers";
+    default: return "unknown status";
+    }
+}
+
+const char *pq_last_error(pq_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int pq_ctx_create(int device, void *hip_stream, pq_ctx **out)
+{
+    if (!out) return PQ_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PQ_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return PQ_ERR_BAD_ARGUMENT;
+    pq_ctx *ctx = new (std::nothrow) pq_ctx;
+    if (!ctx) return PQ_ERR_BAD_ARGUMENT;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) {
+        delete ctx;
+        return PQ_ERR_HIP;
+    }
+    if (hip_stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return PQ_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return PQ_OK;
+}
+
+void pq_ctx_destroy(pq_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 4; ++i)
+        if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int pq_ctx_synchronize(pq_ctx *ctx)
+{
+    if (!ctx) return PQ_ERR_BAD_ARGUMENT;
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    PQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PQ_OK;
+}
+
+// ---- bit-unpack -----------------------------------------------------------
+
+static int bitunpack_dev(pq_ctx *ctx, const void *d_src, size_t src_len, int w, size_t n_groups,
+                         void *d_dst, int bits)
+{
+    if (!ctx || w < 0 || w > bits) return PQ_ERR_BAD_ARGUMENT;
+    if (n_groups == 0) return PQ_OK;
+    if (!d_dst || (w > 0 && !d_src)) return PQ_ERR_BAD_ARGUMENT;
+    if ((uint64_t)n_groups * (uint64_t)w > (uint64_t)src_len) return PQ_ERR_OUT_OF_RANGE;
+    if (reinterpret_cast<uintptr_t>(d_dst) % (bits / 8)) return PQ_ERR_BAD_ARGUMENT;
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    if (bits == 32)
+        PQ_HIP(ctx, pq::launch_bitunpack32(ctx->stream, d_src, src_len, w, n_groups, (int32_t *)d_dst));
+    else
+        PQ_HIP(ctx, pq::launch_bitunpack64(ctx->stream, d_src, src_len, w, n_groups, (int64_t *)d_dst));
+    return PQ_OK;
+}
+
+int pq_bitunpack32_dev(pq_ctx *ctx, const void *d_src, size_t src_len, int w, size_t n_groups,
+                       int32_t *d_dst)
+{
+    return bitunpack_dev(ctx, d_src, src_len, w, n_groups, d_dst, 32);
+}
+
+int pq_bitunpack64_dev(pq_ctx *ctx, const void *d_src, size_t src_len, int w, size_t n_groups,
+                       int64_t *d_dst)
+{
+    return bitunpack_dev(ctx, d_src, src_len, w, n_groups, d_dst, 64);
+}
+
+static int bitunpack_host(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, size_t n_groups,
+                          void *dst, int bits)
+{
+    if (!ctx || w < 0 || w > bits) return PQ_ERR_BAD_ARGUMENT;
+    if (n_groups == 0) return PQ_OK;
+    if (!dst || (w > 0 && !src)) return PQ_ERR_BAD_ARGUMENT;
+    const size_t in_bytes = n_groups * (size_t)w;
+    if (in_bytes > src_len) return PQ_ERR_OUT_OF_RANGE;
+    const size_t out_bytes = n_groups * 8u * (size_t)(bits / 8);
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    int st = ensure_stage(ctx, 0, in_bytes + 16);
+    if (st == PQ_OK) st = ensure_stage(ctx, 1, out_bytes);
+    if (st != PQ_OK) return st;
+    if (in_bytes)
+        PQ_HIP(ctx, hipMemcpyAsync(ctx->stage[0], src, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    st = bitunpack_dev(ctx, ctx->stage[0], in_bytes, w, n_groups, ctx->stage[1], bits);
+    if (st != PQ_OK) return st;
+    PQ_HIP(ctx, hipMemcpyAsync(dst, ctx->stage[1], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PQ_OK;
+}
+
+int pq_bitunpack32(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, size_t n_groups, int32_t *dst)
+{
+    return bitunpack_host(ctx, src, src_len, w, n_groups, dst, 32);
+}
+
+int pq_bitunpack64(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, size_t n_groups, int64_t *dst)
+{
+    return bitunpack_host(ctx, src, src_len, w, n_groups, dst, 64);
+}
+
+// ---- plans ------------------------------------------------------------------
+
+int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_plan **out)
+{
+    if (!ctx || !out || (n_pages && !descs) || n_pages > 0x7fffffffu) return PQ_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    std::vector<uint32_t> ids[4];
+    pq_plan *plan = new (std::nothrow) pq_plan;
+    if (!plan) return PQ_ERR_BAD_ARGUMENT;
+    plan->ctx = ctx;
+    plan->n = n_pages;
+    uint64_t dict_bytes_max = 0;
+    for (size_t i = 0; i < n_pages; ++i) {
+        const pq_page_desc &d = descs[i];
+        const int st = validate(d);
+        if (st != PQ_OK) {
+            delete plan;
+            return st;
+        }
+        ids[group_of(d.kind)].push_back((uint32_t)i);
+        plan->src_need = std::max(plan->src_need, d.src_off + d.src_len);
+        if (d.kind == PQ_KIND_DELTA32 || d.kind == PQ_KIND_DELTA64 ||
+            d.value_kind == PQ_KIND_DELTA32 || d.value_kind == PQ_KIND_DELTA64)
+            plan->has_delta = true;
+        const uint32_t vs = value_size(d);
+        if (vs) plan->values_need = std::max(plan->values_need, d.dst_off + (uint64_t)d.n_values * vs);
+        const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
+        if (page || d.kind == PQ_KIND_LEVELS)
+            plan->levels_need = std::max(plan->levels_need, d.def_off + (uint64_t)4 * d.n_values);
+        if (page) plan->levels_need = std::max(plan->levels_need, d.rep_off + (uint64_t)4 * d.n_values);
+        if (d.kind == PQ_KIND_DICT || (page && d.value_kind == PQ_KIND_DICT)) {
+            const uint64_t db = (uint64_t)d.dict_len * d.elem_size;
+            plan->dict_need = std::max(plan->dict_need, d.dict_off + db);
+            if (db <= pq::kDictLdsMax) dict_bytes_max = std::max(dict_bytes_max, db);
+        }
+    }
+    plan->dict_lds_bytes = (uint32_t)((dict_bytes_max + 15u) & ~15ull);
+
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        delete plan;
+        return PQ_ERR_HIP;
+    }
+    std::vector<uint32_t> all;
+    all.reserve(n_pages);
+    for (int g = 0; g < 4; ++g) {
+        plan->first[g] = (uint32_t)all.size();
+        plan->count[g] = (uint32_t)ids[g].size();
+        all.insert(all.end(), ids[g].begin(), ids[g].end());
+    }
+    if (n_pages) {
+        hipError_t e = hipMalloc((void **)&plan->d_descs, n_pages * sizeof(pq_page_desc));
+        if (e == hipSuccess) e = hipMalloc((void **)&plan->d_ids, n_pages * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&plan->d_results, n_pages * sizeof(pq_page_result));
+        // synchronous copies: the host vectors die with this call
+        if (e == hipSuccess)
+            e = hipMemcpy(plan->d_descs, descs, n_pages * sizeof(pq_page_desc), hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = hipMemcpy(plan->d_ids, all.data(), n_pages * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(plan->d_results, 0xff, n_pages * sizeof(pq_page_result));
+        if (e != hipSuccess) {
+            hip_ok(ctx, e, "pq_plan_create");
+            pq_plan_destroy(plan);
+            return PQ_ERR_HIP;
+        }
+    }
+    *out = plan;
+    return PQ_OK;
+}
+
+void pq_plan_destroy(pq_plan *plan)
+{
+    if (!plan) return;
+    (void)hipSetDevice(plan->ctx->device);
+    (void)hipStreamSynchronize(plan->ctx->stream);
+    if (plan->d_descs) (void)hipFree(plan->d_descs);
+    if (plan->d_ids) (void)hipFree(plan->d_ids);
+    if (plan->d_results) (void)hipFree(plan->d_results);
+    delete plan;
+}
+
+int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_values, size_t values_bytes,
+                void *d_levels, size_t levels_bytes, const void *d_dict, size_t dict_bytes)
+{
+    if (!plan) return PQ_ERR_BAD_ARGUMENT;
+    pq_ctx *ctx = plan->ctx;
+    if (plan->n == 0) return PQ_OK;
+    if (plan->src_need > src_bytes || plan->values_need > values_bytes ||
+        plan->levels_need > levels_bytes || plan->dict_need > dict_bytes)
+        return PQ_ERR_OUT_OF_RANGE;
+    if ((plan->src_need && !d_src) || (plan->values_need && !d_values) ||
+        (plan->levels_need && !d_levels) || (plan->dict_need && !d_dict))
+        return PQ_ERR_BAD_ARGUMENT;
+    // value / level outputs are written with naturally aligned element stores
+    if ((reinterpret_cast<uintptr_t>(d_values) & 7u) || (reinterpret_cast<uintptr_t>(d_levels) & 3u) ||
+        (reinterpret_cast<uintptr_t>(d_dict) & 7u))
+        return PQ_ERR_BAD_ARGUMENT;
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    pq::PageBuffers buf{(const uint8_t *)d_src, (uint8_t *)d_values, (uint8_t *)d_levels,
+                        (const uint8_t *)d_dict};
+    PQ_HIP(ctx, pq::launch_stream_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[0],
+                                        plan->count[0], buf, plan->d_results, plan->dict_lds_bytes));
+    PQ_HIP(ctx, pq::launch_delta_pages(ctx->stream, 32, plan->d_descs, plan->d_ids + plan->first[1],
+                                       plan->count[1], buf, plan->d_results));
+    PQ_HIP(ctx, pq::launch_delta_pages(ctx->stream, 64, plan->d_descs, plan->d_ids + plan->first[2],
+                                       plan->count[2], buf, plan->d_results));
+    PQ_HIP(ctx, pq::launch_data_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[3],
+                                      plan->count[3], buf, plan->d_results, plan->dict_lds_bytes));
+    // groups 1..3 are contiguous in d_ids; pages with a delta layout outside the tiled path
+    // (possible only if the plan holds delta descriptors at all) are completed serially
+    if (plan->has_delta)
+        PQ_HIP(ctx, pq::launch_delta_serial(ctx->stream, plan->d_descs, plan->d_ids + plan->first[1],
+                                            plan->count[1] + plan->count[2] + plan->count[3], buf,
+                                            plan->d_results));
+    return PQ_OK;
+}
+
+int pq_plan_results(pq_plan *plan, pq_page_result *results)
+{
+    if (!plan || (plan->n && !results)) return PQ_ERR_BAD_ARGUMENT;
+    pq_ctx *ctx = plan->ctx;
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    PQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (plan->n)
+        PQ_HIP(ctx, hipMemcpy(results, plan->d_results, plan->n * sizeof(pq_page_result),
+                              hipMemcpyDeviceToHost));
+    return PQ_OK;
+}
+
+// ---- host-memory batch --------------------------------------------------------
+
+int pq_decode_pages(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, const void *src,
+                    size_t src_bytes, void *values, size_t values_bytes, void *levels,
+                    size_t levels_bytes, const void *dict, size_t dict_bytes, pq_page_result *results)
+{
+    if (!ctx || (n_pages && (!descs || !results))) return PQ_ERR_BAD_ARGUMENT;
+    if (n_pages == 0) return PQ_OK;
+    if ((src_bytes && !src) || (values_bytes && !values) || (levels_bytes && !levels) ||
+        (dict_bytes && !dict))
+        return PQ_ERR_BAD_ARGUMENT;
+    pq_plan *plan = nullptr;
+    int st = pq_plan_create(ctx, descs, n_pages, &plan);
+    if (st != PQ_OK) return st;
+    auto done = [&](int code) {
+        pq_plan_destroy(plan);
+        return code;
+    };
+    const size_t sizes[4] = {src_bytes, values_bytes, levels_bytes, dict_bytes};
+    for (int i = 0; i < 4; ++i)
+        if ((st = ensure_stage(ctx, i, sizes[i] + 16)) != PQ_OK) return done(st);
+    if (src_bytes && !hip_ok(ctx, hipMemcpyAsync(ctx->stage[0], src, src_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D src"))
+        return done(PQ_ERR_HIP);
+    if (dict_bytes && !hip_ok(ctx, hipMemcpyAsync(ctx->stage[3], dict, dict_bytes, hipMemcpyHostToDevice, ctx->stream), "H2D dict"))
+        return done(PQ_ERR_HIP);
+    st = pq_plan_run(plan, ctx->stage[0], src_bytes, ctx->stage[1], values_bytes, ctx->stage[2], levels_bytes,
+                     ctx->stage[3], dict_bytes);
+    if (st != PQ_OK) return done(st);
+    if (values_bytes && !hip_ok(ctx, hipMemcpyAsync(values, ctx->stage[1], values_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H values"))
+        return done(PQ_ERR_HIP);
+    if (levels_bytes && !hip_ok(ctx, hipMemcpyAsync(levels, ctx->stage[2], levels_bytes, hipMemcpyDeviceToHost, ctx->stream), "D2H levels"))
+        return done(PQ_ERR_HIP);
+    st = pq_plan_results(plan, results);
+    return done(st);
+}
+
+// ---- single-stream conveniences -------------------------------------------------
+
+static int one_page(pq_ctx *ctx, pq_page_desc &d, const void *src, size_t src_len, void *values,
+                    size_t values_bytes, void *levels, size_t levels_bytes, const void *dict,
+                    size_t dict_bytes, pq_page_result *r)
+{
+    d.src_off = 0;
+    d.src_len = src_len;
+    return pq_decode_pages(ctx, &d, 1, src, src_len, values, values_bytes, levels, levels_bytes, dict,
+                           dict_bytes, r);
+}
+
+int pq_hybrid_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, int length_prefixed,
+                     uint32_t n, int32_t *dst, uint32_t *n_decoded, uint64_t *consumed)
+{
+    if (w < 0 || w > 32) return PQ_ERR_BAD_ARGUMENT;
+    pq_page_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.kind = PQ_KIND_HYBRID;
+    d.flags = length_prefixed ? PQ_FLAG_LENGTH_PREFIXED : 0;
+    d.bit_width = (uint32_t)w;
+    d.n_values = n;
+    pq_page_result r;
+    const int st = one_page(ctx, d, src, src_len, dst, (size_t)n * 4, nullptr, 0, nullptr, 0, &r);
+    if (st != PQ_OK) return st;
+    if (n_decoded) *n_decoded = r.n_decoded;
+    if (consumed) *consumed = r.consumed;
+    return r.status;
+}
+
+int pq_dict_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, const void *dict, uint32_t dict_len,
+                   uint32_t elem_size, uint32_t n, void *dst, uint32_t *n_decoded, uint64_t *consumed)
+{
+    pq_page_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.kind = PQ_KIND_DICT;
+    d.n_values = n;
+    d.elem_size = elem_size;
+    d.dict_len = dict_len;
+    pq_page_result r;
+    const int st = one_page(ctx, d, src, src_len, dst, (size_t)n * elem_size, nullptr, 0, dict,
+                            (size_t)dict_len * elem_size, &r);
+    if (st != PQ_OK) return st;
+    if (n_decoded) *n_decoded = r.n_decoded;
+    if (consumed) *consumed = r.consumed;
+    return r.status;
+}
+
+int pq_levels_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t max_level, int mode,
+                     uint32_t n, int32_t *levels, uint32_t *not_null, uint64_t *consumed)
+{
+    if (mode < 0 || mode > 2) return PQ_ERR_BAD_ARGUMENT;
+    pq_page_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.kind = PQ_KIND_LEVELS;
+    d.max_def = max_level;
+    d.n_values = n;
+    if (mode == 0) d.flags = PQ_FLAG_LEVELS_CONST;
+    if (mode == 1) d.flags = PQ_FLAG_LENGTH_PREFIXED;
+    if (mode == 2 && src_len == 0) d.flags = PQ_FLAG_NO_INIT;
+    pq_page_result r;
+    const int st = one_page(ctx, d, src, src_len, nullptr, 0, levels, (size_t)n * 4, nullptr, 0, &r);
+    if (st != PQ_OK) return st;
+    if (not_null) *not_null = r.not_null;
+    if (consumed) *consumed = r.consumed;
+    return r.status;
+}
+
+static int delta_host(pq_ctx *ctx, uint32_t kind, const uint8_t *src, size_t src_len, uint32_t n, void *dst,
+                      size_t elem, uint32_t *n_decoded, uint64_t *consumed)
+{
+    pq_page_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.kind = kind;
+    d.n_values = n;
+    pq_page_result r;
+    const int st = one_page(ctx, d, src, src_len, dst, (size_t)n * elem, nullptr, 0, nullptr, 0, &r);
+    if (st != PQ_OK) return st;
+    if (n_decoded) *n_decoded = r.n_decoded;
+    if (consumed) *consumed = r.consumed;
+    return r.status;
+}
+
+int pq_delta_decode32(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n, int32_t *dst,
+                      uint32_t *n_decoded, uint64_t *consumed)
+{
+    return delta_host(ctx, PQ_KIND_DELTA32, src, src_len, n, dst, 4, n_decoded, consumed);
+}
+
+int pq_delta_decode64(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n, int64_t *dst,
+                      uint32_t *n_decoded, uint64_t *consumed)
+{
+    return delta_host(ctx, PQ_KIND_DELTA64, src, src_len, n, dst, 8, n_decoded, consumed);
+}
+
+} // extern "C"

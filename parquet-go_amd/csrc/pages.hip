@@ -1,0 +1,491 @@
+// pages.hip — one workgroup per page descriptor.
+//
+// Three kernels share the stream decoders of hybrid_stream.hpp / delta_stream.hpp:
+//   stream_pages_kernel : PQ_KIND_HYBRID, PQ_KIND_DICT, PQ_KIND_LEVELS
+//   delta_pages_kernel  : PQ_KIND_DELTA32 / PQ_KIND_DELTA64
+//   data_pages_kernel   : PQ_KIND_PAGE_V1 / PQ_KIND_PAGE_V2 (rep levels, def levels,
+//                         then exactly not_null values), the order and the error
+//                         precedence of layout/page-v1.go:40-116 and
+//                         layout/page-v2.go:42-149.
+// Pages are independent (each data page re-creates its decoders,
+// layout/chunk.go:196-209), so there is no inter-workgroup traffic of any kind.
+#include "delta_stream.hpp"
+#include "hybrid_stream.hpp"
+#include "pq_launch.hpp"
+
+namespace pq {
+
+constexpr uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
+
+union PageShared {
+    HybridShared hy;
+    DeltaShared dl;
+};
+
+extern __shared__ __attribute__((aligned(16))) uint8_t pq_smem[];
+
+__device__ __forceinline__ uint32_t load_le32(const uint8_t *p)
+{
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+// ---- one hybrid section with the Init / InitSize / never-initialised variants ----
+
+struct Section {
+    const uint8_t *S; // first byte of the hybrid stream proper
+    int64_t len;      // bytes the decoder may read
+    int32_t init_status;
+    uint32_t consumed_by_init; // bytes of the enclosing reader taken by InitSize
+    bool no_reader;
+};
+
+// InitSize on a reader positioned at S with `avail` bytes left
+// (encoding/hybrid-decoder.go:57-68): nothing is read when w == 0; otherwise a u32
+// LE byte count, then the decoder owns the next min(count, remaining) bytes.
+__device__ __forceinline__ Section section_init_size(const uint8_t *S, int64_t avail, uint32_t w)
+{
+    Section s{S, 0, PQ_OK, 0, false};
+    if (w == 0) return s;
+    if (avail < 4) {
+        s.init_status = avail <= 0 ? PQ_EOF : PQ_UNEXPECTED_EOF;
+        return s;
+    }
+    const uint32_t size = load_le32(S);
+    s.S = S + 4;
+    s.len = min((int64_t)size, avail - 4);
+    s.consumed_by_init = 4u + (uint32_t)s.len;
+    return s;
+}
+
+template <int MODE, typename OutT>
+__device__ __forceinline__ HybridResult run_section(HybridShared &sh, const Section &sec, uint32_t w, uint32_t n,
+                                           OutT *dst, const OutT *dict, uint32_t dict_len,
+                                           uint32_t max_level)
+{
+    if (sec.no_reader && w != 0) {
+        // "reader is not initialized" on the first pull (hybrid-decoder.go:78-80)
+        HybridResult r{n > 0 ? PQ_NOT_INITIALIZED : PQ_OK, 0, 0, 0};
+        return r;
+    }
+    return hybrid_stream<MODE, OutT>(sh, sec.S, sec.len, w, n, dst, dict, dict_len, max_level);
+}
+
+// Levels from ConstDecoder(0) (encoding/const.go:7-19): n zeros, nothing read.
+__device__ __forceinline__ HybridResult const_levels(uint32_t *dst, uint32_t n, uint32_t max_level)
+{
+    for (uint32_t i = threadIdx.x; i < n; i += kWG) dst[i] = 0;
+    HybridResult r{PQ_OK, n, max_level == 0 ? n : 0u, 0};
+    return r;
+}
+
+// Copy a dictionary into LDS when it fits the budget; returns true if cached.
+__device__ __forceinline__ bool cache_dict(uint32_t *ldict, const uint8_t *gdict, uint32_t bytes, uint32_t budget)
+{
+    if (bytes == 0 || bytes > budget) return false;
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(gdict);
+    for (uint32_t i = threadIdx.x; i < bytes / 4u; i += kWG) ldict[i] = g[i];
+    __syncthreads();
+    return true;
+}
+
+// DictDecoder over [S, S+len): bit-width byte, then an unprefixed hybrid stream
+// (types/dict.go:66-117).  init_status reports Init alone.
+template <typename OutT>
+__device__ __forceinline__ HybridResult dict_values(HybridShared &sh, const uint8_t *S, int64_t len, uint32_t n,
+                                           OutT *dst, const OutT *gdict, const OutT *ldict,
+                                           bool in_lds, uint32_t dict_len, int32_t *init_status)
+{
+    HybridResult r{PQ_OK, 0, 0, 0};
+    if (len <= 0) {
+        *init_status = PQ_EOF;
+        r.status = PQ_EOF;
+        return r;
+    }
+    const uint32_t w = S[0];
+    if (w > 32u) {
+        *init_status = PQ_DICT_INVALID_WIDTH;
+        r.status = PQ_DICT_INVALID_WIDTH;
+        r.consumed = 1;
+        return r;
+    }
+    *init_status = PQ_OK;
+    if (in_lds)
+        r = hybrid_stream<HY_DICT, OutT>(sh, S + 1, len - 1, w, n, dst, ldict, dict_len, 0);
+    else
+        r = hybrid_stream<HY_DICT, OutT>(sh, S + 1, len - 1, w, n, dst, gdict, dict_len, 0);
+    r.consumed += 1;
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kWG) void stream_pages_kernel(const pq_page_desc *__restrict__ descs,
+                                                           const uint32_t *__restrict__ ids,
+                                                           PageBuffers buf,
+                                                           pq_page_result *__restrict__ results,
+                                                           uint32_t dict_lds_bytes)
+{
+    HybridShared &sh = *reinterpret_cast<HybridShared *>(pq_smem);
+    uint32_t *ldict = reinterpret_cast<uint32_t *>(pq_smem + align16(sizeof(HybridShared)));
+    const uint32_t page = ids[blockIdx.x];
+    const pq_page_desc d = descs[page];
+    const uint8_t *S = buf.src + d.src_off;
+    const int64_t len = (int64_t)d.src_len;
+    const uint32_t n = d.n_values;
+
+    HybridResult r{PQ_OK, 0, 0, 0};
+    uint32_t extra = 0;
+    if (d.kind == PQ_KIND_HYBRID || d.kind == PQ_KIND_LEVELS) {
+        const bool levels = d.kind == PQ_KIND_LEVELS;
+        const uint32_t w = levels ? bits_len16(d.max_def) : d.bit_width;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(levels ? buf.levels + d.def_off : buf.values + d.dst_off);
+        if (levels && (d.flags & PQ_FLAG_LEVELS_CONST)) {
+            r = const_levels(dst, n, d.max_def);
+        } else {
+            Section sec{S, len, PQ_OK, 0, (d.flags & PQ_FLAG_NO_INIT) != 0};
+            if (d.flags & PQ_FLAG_LENGTH_PREFIXED) sec = section_init_size(S, len, w);
+            if (sec.init_status != PQ_OK) {
+                r.status = sec.init_status;
+            } else if (levels) {
+                r = run_section<HY_LEVELS, uint32_t>(sh, sec, w, n, dst, nullptr, 0, d.max_def);
+                // decodePackedArray returns (nil, 0, err) on any error (layout/helpers.go:78-80)
+                if (r.status != PQ_OK) { r.n_decoded = 0; r.count_max = 0; }
+            } else {
+                r = run_section<HY_RAW, uint32_t>(sh, sec, w, n, dst, nullptr, 0, 0);
+            }
+            if (d.flags & PQ_FLAG_LENGTH_PREFIXED) {
+                // the buffered decoder slurped its whole section at InitSize
+                r.consumed = sec.consumed_by_init;
+            }
+        }
+    } else { // PQ_KIND_DICT
+        const uint8_t *gd = buf.dict + d.dict_off;
+        const uint32_t dbytes = d.dict_len * d.elem_size;
+        const bool in_lds = cache_dict(ldict, gd, dbytes, dict_lds_bytes);
+        int32_t init_status;
+        if (d.elem_size == 8)
+            r = dict_values<uint64_t>(sh, S, len, n, reinterpret_cast<uint64_t *>(buf.values + d.dst_off),
+                                      reinterpret_cast<const uint64_t *>(gd),
+                                      reinterpret_cast<const uint64_t *>(ldict), in_lds, d.dict_len,
+                                      &init_status);
+        else
+            r = dict_values<uint32_t>(sh, S, len, n, reinterpret_cast<uint32_t *>(buf.values + d.dst_off),
+                                      reinterpret_cast<const uint32_t *>(gd),
+                                      reinterpret_cast<const uint32_t *>(ldict), in_lds, d.dict_len,
+                                      &init_status);
+        (void)init_status;
+    }
+    (void)extra;
+    if (threadIdx.x == 0) {
+        pq_page_result out;
+        out.status = r.status;
+        out.stage = PQ_STAGE_NONE;
+        out.detail = 0;
+        out.n_decoded = r.n_decoded;
+        out.not_null = r.count_max;
+        out.n_levels = 0;
+        out.consumed = r.consumed;
+        results[page] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------
+
+// delta_stream reports status kNeedSerial for layouts outside its tiled path; the
+// page is then finished by delta_serial_kernel, launched right behind.
+constexpr int32_t kNeedSerial = -1;
+
+template <typename UT>
+__global__ __launch_bounds__(kWG) void delta_pages_kernel(const pq_page_desc *__restrict__ descs,
+                                                          const uint32_t *__restrict__ ids,
+                                                          PageBuffers buf,
+                                                          pq_page_result *__restrict__ results)
+{
+    __shared__ DeltaShared sh;
+    const uint32_t page = ids[blockIdx.x];
+    const pq_page_desc d = descs[page];
+    const DeltaResult r = delta_stream<UT>(sh, buf.src + d.src_off, (int64_t)d.src_len, d.n_values,
+                                           reinterpret_cast<UT *>(buf.values + d.dst_off));
+    if (threadIdx.x == 0) {
+        pq_page_result out;
+        out.status = r.status;
+        out.stage = PQ_STAGE_NONE;
+        out.detail = 0;
+        out.n_decoded = r.n_decoded;
+        out.not_null = 0;
+        out.n_levels = 0;
+        out.consumed = r.consumed;
+        results[page] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------
+
+// Error precedence of read() followed by ReadValues (layout/page-v1.go:40-116).
+__device__ __forceinline__ void finish_page(pq_page_result &out, int32_t v_init, int32_t v_status, uint32_t v_count,
+                                   int32_t lvl_status, int32_t lvl_stage, uint32_t not_null, uint32_t nvals,
+                                   uint32_t size)
+{
+    if (v_init != PQ_OK) { // read() failed: ReadValues never ran
+        out.status = v_init;
+        out.stage = PQ_STAGE_VALUES_INIT;
+    } else if (lvl_status != PQ_OK) {
+        out.status = lvl_status;
+        out.stage = lvl_stage;
+    } else {
+        out.not_null = not_null;
+        out.n_decoded = v_count;
+        if (nvals != 0 && v_status != PQ_OK) { // any error, io.EOF included (page-v1.go:103-110)
+            out.status = PQ_PAGE_VALUES_FAILED;
+            out.detail = v_status;
+            out.stage = PQ_STAGE_VALUES;
+        } else {
+            out.n_levels = size;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kWG) void data_pages_kernel(const pq_page_desc *__restrict__ descs,
+                                                         const uint32_t *__restrict__ ids,
+                                                         PageBuffers buf,
+                                                         pq_page_result *__restrict__ results,
+                                                         uint32_t dict_lds_bytes)
+{
+    PageShared &sh = *reinterpret_cast<PageShared *>(pq_smem);
+    uint32_t *ldict = reinterpret_cast<uint32_t *>(pq_smem + align16(sizeof(PageShared)));
+    const uint32_t page = ids[blockIdx.x];
+    const pq_page_desc d = descs[page];
+    const uint8_t *S = buf.src + d.src_off;
+    const int64_t len = (int64_t)d.src_len;
+    const uint32_t size = d.n_values;
+    uint32_t *rep_dst = reinterpret_cast<uint32_t *>(buf.levels + d.rep_off);
+    uint32_t *def_dst = reinterpret_cast<uint32_t *>(buf.levels + d.def_off);
+
+    pq_page_result out;
+    out.status = PQ_OK;
+    out.stage = PQ_STAGE_NONE;
+    out.detail = 0;
+    out.n_decoded = 0;
+    out.not_null = 0;
+    out.n_levels = 0;
+    out.consumed = 0;
+
+    // ---- read(): where each decoder's bytes are ----
+    const bool konst = d.max_rep == 0; // layout/chunk.go:111-124: both level decoders become ConstDecoder(0)
+    const uint32_t wr = bits_len16(d.max_rep), wd = bits_len16(d.max_def);
+    Section rep{S, 0, PQ_OK, 0, false}, def{S, 0, PQ_OK, 0, false};
+    int64_t vpos = 0; // where the values decoder starts
+    if (!konst) {
+        if (d.kind == PQ_KIND_PAGE_V1) {
+            rep = section_init_size(S, len, wr);
+            if (rep.init_status != PQ_OK) {
+                out.status = rep.init_status;
+                out.stage = PQ_STAGE_REP_INIT;
+            } else {
+                vpos = rep.consumed_by_init;
+                def = section_init_size(S + vpos, len - vpos, wd);
+                if (def.init_status != PQ_OK) {
+                    out.status = def.init_status;
+                    out.stage = PQ_STAGE_DEF_INIT;
+                } else {
+                    vpos += def.consumed_by_init;
+                }
+            }
+        } else {
+            const int64_t lv = (int64_t)d.rep_len + (int64_t)d.def_len;
+            if (lv > 0) {
+                if (lv > len) { // io.ReadFull of the level bytes (page-v2.go:87-90)
+                    out.status = len <= 0 ? PQ_EOF : PQ_UNEXPECTED_EOF;
+                    out.stage = PQ_STAGE_REP_INIT;
+                }
+                rep.S = S;
+                rep.len = d.rep_len;
+                rep.no_reader = d.rep_len == 0;
+                def.S = S + d.rep_len;
+                def.len = d.def_len;
+                def.no_reader = d.def_len == 0;
+                vpos = lv;
+            } else {
+                rep.no_reader = true;
+                def.no_reader = true;
+            }
+        }
+    } else if (d.kind == PQ_KIND_PAGE_V2) {
+        // ConstDecoder.Init ignores its bytes, but the level bytes are still skipped
+        const int64_t lv = (int64_t)d.rep_len + (int64_t)d.def_len;
+        if (lv > len) {
+            out.status = len <= 0 ? PQ_EOF : PQ_UNEXPECTED_EOF;
+            out.stage = PQ_STAGE_REP_INIT;
+        }
+        vpos = lv;
+    }
+
+    if (out.status != PQ_OK) { // failed before the values decoder was initialised
+        if (threadIdx.x == 0) results[page] = out;
+        return;
+    }
+
+    // ---- ReadValues: levels ----
+    int32_t lvl_status = PQ_OK, lvl_stage = PQ_STAGE_NONE;
+    uint32_t not_null = 0;
+    if (size != 0) {
+        HybridResult rr = konst ? const_levels(rep_dst, size, d.max_rep)
+                                : run_section<HY_LEVELS, uint32_t>(sh.hy, rep, wr, size, rep_dst, nullptr, 0, d.max_rep);
+        if (rr.status != PQ_OK) {
+            lvl_status = rr.status;
+            lvl_stage = PQ_STAGE_REP;
+        } else {
+            HybridResult dr = konst ? const_levels(def_dst, size, d.max_def)
+                                    : run_section<HY_LEVELS, uint32_t>(sh.hy, def, wd, size, def_dst, nullptr, 0, d.max_def);
+            if (dr.status != PQ_OK) {
+                lvl_status = dr.status;
+                lvl_stage = PQ_STAGE_DEF;
+            } else {
+                not_null = dr.count_max;
+            }
+        }
+    }
+    const uint32_t nvals = (lvl_status == PQ_OK) ? not_null : 0;
+
+    // ---- values: Init always runs (read()), DecodeValues only for not_null != 0 ----
+    const uint8_t *VS = S + vpos;
+    const int64_t vlen = len - vpos;
+    int32_t v_init = PQ_OK, v_status = PQ_OK;
+    uint32_t v_count = 0;
+    if (d.value_kind == PQ_KIND_DICT) {
+        const uint8_t *gd = buf.dict + d.dict_off;
+        const bool in_lds = cache_dict(ldict, gd, d.dict_len * d.elem_size, dict_lds_bytes);
+        HybridResult vr;
+        if (d.elem_size == 8)
+            vr = dict_values<uint64_t>(sh.hy, VS, vlen, nvals, reinterpret_cast<uint64_t *>(buf.values + d.dst_off),
+                                       reinterpret_cast<const uint64_t *>(gd),
+                                       reinterpret_cast<const uint64_t *>(ldict), in_lds, d.dict_len, &v_init);
+        else
+            vr = dict_values<uint32_t>(sh.hy, VS, vlen, nvals, reinterpret_cast<uint32_t *>(buf.values + d.dst_off),
+                                       reinterpret_cast<const uint32_t *>(gd),
+                                       reinterpret_cast<const uint32_t *>(ldict), in_lds, d.dict_len, &v_init);
+        v_status = vr.status;
+        v_count = vr.n_decoded;
+    } else {
+        DeltaResult vr;
+        if (d.value_kind == PQ_KIND_DELTA64)
+            vr = delta_stream<uint64_t>(sh.dl, VS, vlen, nvals, reinterpret_cast<uint64_t *>(buf.values + d.dst_off));
+        else
+            vr = delta_stream<uint32_t>(sh.dl, VS, vlen, nvals, reinterpret_cast<uint32_t *>(buf.values + d.dst_off));
+        if (vr.status == kNeedSerial) {
+            // park what ReadValues knows so far; delta_serial_kernel completes the page
+            if (threadIdx.x == 0) {
+                out.status = kNeedSerial;
+                out.stage = lvl_stage;
+                out.detail = lvl_status;
+                out.n_decoded = nvals;
+                out.not_null = not_null;
+                out.n_levels = size;
+                out.consumed = (uint64_t)vpos;
+                results[page] = out;
+            }
+            return;
+        }
+        if (vr.init_failed) v_init = vr.status;
+        v_status = vr.status;
+        v_count = vr.n_decoded;
+    }
+
+    finish_page(out, v_init, v_status, v_count, lvl_status, lvl_stage, not_null, nvals, size);
+    if (threadIdx.x == 0) results[page] = out;
+}
+
+// Completes the delta pages whose layout the tiled path declined: one lane per page.
+__global__ __launch_bounds__(kWave) void delta_serial_kernel(const pq_page_desc *__restrict__ descs,
+                                                             const uint32_t *__restrict__ ids, uint32_t count,
+                                                             PageBuffers buf,
+                                                             pq_page_result *__restrict__ results)
+{
+    const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t page = ids[i];
+    pq_page_result out = results[page];
+    if (out.status != kNeedSerial) return;
+    const pq_page_desc d = descs[page];
+    const bool is_page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
+    const uint32_t vk = is_page ? d.value_kind : d.kind;
+    const int64_t vpos = is_page ? (int64_t)out.consumed : 0;
+    const uint32_t n = is_page ? out.n_decoded : d.n_values;
+    const uint8_t *S = buf.src + d.src_off + vpos;
+    const int64_t len = (int64_t)d.src_len - vpos;
+    DeltaResult r;
+    if (vk == PQ_KIND_DELTA64)
+        r = delta_serial<uint64_t>(S, len, n, reinterpret_cast<uint64_t *>(buf.values + d.dst_off));
+    else
+        r = delta_serial<uint32_t>(S, len, n, reinterpret_cast<uint32_t *>(buf.values + d.dst_off));
+    if (!is_page) {
+        out.status = r.status;
+        out.stage = PQ_STAGE_NONE;
+        out.detail = 0;
+        out.n_decoded = r.n_decoded;
+        out.not_null = 0;
+        out.n_levels = 0;
+        out.consumed = r.consumed;
+    } else {
+        const int32_t lvl_stage = out.stage, lvl_status = out.detail;
+        const uint32_t not_null = out.not_null, size = out.n_levels;
+        out.status = PQ_OK;
+        out.stage = PQ_STAGE_NONE;
+        out.detail = 0;
+        out.n_decoded = 0;
+        out.not_null = 0;
+        out.n_levels = 0;
+        out.consumed = 0;
+        finish_page(out, r.init_failed ? r.status : PQ_OK, r.status, r.n_decoded, lvl_status, lvl_stage,
+                    not_null, n, size);
+    }
+    results[page] = out;
+}
+
+// ---------------------------------------------------------------------------
+
+hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
+                               uint32_t count, PageBuffers buf, pq_page_result *d_results,
+                               uint32_t dict_lds_bytes)
+{
+    if (count == 0) return hipSuccess;
+    const size_t shmem = align16(sizeof(HybridShared)) + dict_lds_bytes;
+    hipLaunchKernelGGL(stream_pages_kernel, dim3(count), dim3(kWG), shmem, s, d_descs, d_ids, buf, d_results,
+                       dict_lds_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_delta_pages(hipStream_t s, int bits, const pq_page_desc *d_descs, const uint32_t *d_ids,
+                              uint32_t count, PageBuffers buf, pq_page_result *d_results)
+{
+    if (count == 0) return hipSuccess;
+    if (bits == 64)
+        hipLaunchKernelGGL(delta_pages_kernel<uint64_t>, dim3(count), dim3(kWG), 0, s, d_descs, d_ids, buf,
+                           d_results);
+    else
+        hipLaunchKernelGGL(delta_pages_kernel<uint32_t>, dim3(count), dim3(kWG), 0, s, d_descs, d_ids, buf,
+                           d_results);
+    return hipGetLastError();
+}
+
+hipError_t launch_delta_serial(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
+                               uint32_t count, PageBuffers buf, pq_page_result *d_results)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(delta_serial_kernel, dim3((count + kWave - 1) / kWave), dim3(kWave), 0, s, d_descs, d_ids,
+                       count, buf, d_results);
+    return hipGetLastError();
+}
+
+hipError_t launch_data_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
+                             uint32_t count, PageBuffers buf, pq_page_result *d_results,
+                             uint32_t dict_lds_bytes)
+{
+    if (count == 0) return hipSuccess;
+    const size_t shmem = align16(sizeof(PageShared)) + dict_lds_bytes;
+    hipLaunchKernelGGL(data_pages_kernel, dim3(count), dim3(kWG), shmem, s, d_descs, d_ids, buf, d_results,
+                       dict_lds_bytes);
+    return hipGetLastError();
+}
+
+} // namespace pq

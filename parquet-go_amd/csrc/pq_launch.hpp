@@ -1,0 +1,44 @@
+// pq_launch.hpp — host-side launchers of the gfx950 kernels (internal to the library).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "pqdecode.h"
+
+namespace pq {
+
+hipError_t launch_bitunpack32(hipStream_t s, const void *d_src, size_t src_len, int w, size_t n_groups,
+                              int32_t *d_dst);
+hipError_t launch_bitunpack64(hipStream_t s, const void *d_src, size_t src_len, int w, size_t n_groups,
+                              int64_t *d_dst);
+
+// Buffers every page kernel works on (device pointers).
+struct PageBuffers {
+    const uint8_t *src;
+    uint8_t *values;
+    uint8_t *levels;
+    const uint8_t *dict;
+};
+
+// ids: device array of `count` descriptor indices handled by this launch.
+// dict_lds_bytes: LDS set aside for caching a page's dictionary (0 = gather from global).
+hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
+                               uint32_t count, PageBuffers buf, pq_page_result *d_results,
+                               uint32_t dict_lds_bytes);
+hipError_t launch_delta_pages(hipStream_t s, int bits, const pq_page_desc *d_descs,
+                              const uint32_t *d_ids, uint32_t count, PageBuffers buf,
+                              pq_page_result *d_results);
+hipError_t launch_data_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
+                             uint32_t count, PageBuffers buf, pq_page_result *d_results,
+                             uint32_t dict_lds_bytes);
+
+// Finishes, one lane per page, the delta descriptors among ids[0..count) that the
+// tiled kernels marked as needing the serial path; a no-op for all others.
+hipError_t launch_delta_serial(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
+                               uint32_t count, PageBuffers buf, pq_page_result *d_results);
+
+constexpr uint32_t kDictLdsMax = 48u * 1024u;
+
+} // namespace pq
