@@ -71,6 +71,14 @@ def load():
             raise RuntimeError(
                 "libpqdecode.so is not built: run `make -C parquet-go_amd/csrc` "
                 "(or __graft_entry__.build()); there is no fallback decode path")
+        # One HIP runtime per process: PyTorch ships its own libamdhip64 (soname
+        # libamdhip64.so.7) and its extension libraries ask for it by file name, so if
+        # the system copy were loaded first torch would bring in a second runtime that
+        # finds no GPU.  Importing torch first makes this library bind to torch's copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         lib.pq_status_string.restype = C.c_char_p
         lib.pq_last_error.restype = C.c_char_p

@@ -156,6 +156,10 @@ __global__ __launch_bounds__(kWG) void stream_pages_kernel(const pq_page_desc *_
             if (d.flags & PQ_FLAG_LENGTH_PREFIXED) {
                 // the buffered decoder slurped its whole section at InitSize
                 r.consumed = sec.consumed_by_init;
+            } else if (levels && !sec.no_reader) {
+                // level decoders are buffered (layout/chunk.go:87,103): Init reads the
+                // whole section it is given, whatever the width
+                r.consumed = (uint64_t)len;
             }
         }
     } else { // PQ_KIND_DICT

@@ -134,5 +134,5 @@ def _decode_with_canary(ctx, descs, src, val_bytes, lvl_bytes, dictionary):
 
 
 def guard_ok(arr):
-    a = np.asarray(arr).view(np.uint8)
+    a = np.atleast_1d(np.asarray(arr)).view(np.uint8)
     return bool((a == CANARY).all())
