@@ -69,6 +69,12 @@ typedef struct pq_ctx pq_ctx;
 int pq_ctx_create(int device, void *hip_stream, pq_ctx **out);
 void pq_ctx_destroy(pq_ctx *ctx);
 int pq_ctx_synchronize(pq_ctx *ctx);
+/* Tuning knobs (no counterpart in the reference).
+ * PQ_OPT_DELTA_WAVE_MIN_PAGES: a batch with at least this many delta descriptors of one
+ * element size is decoded one wave per page (best when pages outnumber the chip's
+ * wave slots); smaller batches use one workgroup per page.  Default 2048. */
+#define PQ_OPT_DELTA_WAVE_MIN_PAGES 1
+int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value);
 const char *pq_status_string(int status);
 const char *pq_last_error(pq_ctx *ctx); /* text of the last HIP failure on ctx */
 int pq_version(void);

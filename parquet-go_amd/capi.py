@@ -21,11 +21,13 @@ ERR_BAD_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_OUT_OF_RANGE = 100, 101, 102, 103
 
 KIND_HYBRID, KIND_DICT, KIND_LEVELS, KIND_DELTA32, KIND_DELTA64, KIND_PAGE_V1, KIND_PAGE_V2 = range(1, 8)
 FLAG_LENGTH_PREFIXED, FLAG_LEVELS_CONST, FLAG_NO_INIT = 1, 2, 4
+OPT_DELTA_WAVE_MIN_PAGES = 1
 
 STAGE_NONE, STAGE_REP_INIT, STAGE_DEF_INIT, STAGE_VALUES_INIT, STAGE_REP, STAGE_DEF, STAGE_VALUES = range(7)
 
 EXPORTS = [
-    "pq_ctx_create", "pq_ctx_destroy", "pq_ctx_synchronize", "pq_status_string", "pq_last_error",
+    "pq_ctx_create", "pq_ctx_destroy", "pq_ctx_synchronize", "pq_ctx_set_option", "pq_status_string",
+    "pq_last_error",
     "pq_version", "pq_bitunpack32_dev", "pq_bitunpack64_dev", "pq_bitunpack32", "pq_bitunpack64",
     "pq_plan_create", "pq_plan_run", "pq_plan_results", "pq_plan_destroy", "pq_decode_pages",
     "pq_hybrid_decode", "pq_dict_decode", "pq_levels_decode", "pq_delta_decode32",
@@ -89,6 +91,7 @@ def load():
         lib.pq_plan_destroy.argtypes = [C.c_void_p]
         lib.pq_ctx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         lib.pq_ctx_synchronize.argtypes = [C.c_void_p]
+        lib.pq_ctx_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int64]
         lib.pq_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         lib.pq_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -166,6 +169,9 @@ class Context:
 
     def synchronize(self):
         self._check(self._lib.pq_ctx_synchronize(self._h))
+
+    def set_option(self, option, value):
+        self._check(self._lib.pq_ctx_set_option(self._h, int(option), int(value)), "set_option")
 
     # ---- host-memory entry points (numpy in / numpy out) ----
     def bitunpack(self, src, w, n_groups, bits=32):

@@ -20,6 +20,7 @@ struct pq_ctx {
     bool own_stream = false;
     std::string last_error;
     // grow-only device staging used by the host-pointer entry points
+    uint32_t delta_wave_min_pages = 2048; // 256 CUs x 8 waves
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_cap[4] = {0, 0, 0, 0};
 };
@@ -199,6 +200,18 @@ int pq_ctx_synchronize(pq_ctx *ctx)
     return PQ_OK;
 }
 
+int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value)
+{
+    if (!ctx) return PQ_ERR_BAD_ARGUMENT;
+    switch (option) {
+    case PQ_OPT_DELTA_WAVE_MIN_PAGES:
+        if (value < 0) return PQ_ERR_BAD_ARGUMENT;
+        ctx->delta_wave_min_pages = value > 0xffffffffll ? 0xffffffffu : (uint32_t)value;
+        return PQ_OK;
+    default: return PQ_ERR_BAD_ARGUMENT;
+    }
+}
+
 // ---- bit-unpack -----------------------------------------------------------
 
 static int bitunpack_dev(pq_ctx *ctx, const void *d_src, size_t src_len, int w, size_t n_groups,
@@ -363,9 +376,9 @@ int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_valu
     PQ_HIP(ctx, pq::launch_stream_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[0],
                                         plan->count[0], buf, plan->d_results, plan->dict_lds_bytes));
     PQ_HIP(ctx, pq::launch_delta_pages(ctx->stream, 32, plan->d_descs, plan->d_ids + plan->first[1],
-                                       plan->count[1], buf, plan->d_results));
+                                       plan->count[1], buf, plan->d_results, ctx->delta_wave_min_pages));
     PQ_HIP(ctx, pq::launch_delta_pages(ctx->stream, 64, plan->d_descs, plan->d_ids + plan->first[2],
-                                       plan->count[2], buf, plan->d_results));
+                                       plan->count[2], buf, plan->d_results, ctx->delta_wave_min_pages));
     PQ_HIP(ctx, pq::launch_data_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[3],
                                       plan->count[3], buf, plan->d_results, plan->dict_lds_bytes));
     // groups 1..3 are contiguous in d_ids; pages with a delta layout outside the tiled path

@@ -10,6 +10,7 @@
 // Pages are independent (each data page re-creates its decoders,
 // layout/chunk.go:196-209), so there is no inter-workgroup traffic of any kind.
 #include "delta_stream.hpp"
+#include "delta_wave.hpp"
 #include "hybrid_stream.hpp"
 #include "pq_launch.hpp"
 
@@ -201,16 +202,50 @@ constexpr int32_t kNeedSerial = -1;
 
 template <typename UT>
 __global__ __launch_bounds__(kWG) void delta_pages_kernel(const pq_page_desc *__restrict__ descs,
-                                                          const uint32_t *__restrict__ ids,
-                                                          PageBuffers buf,
-                                                          pq_page_result *__restrict__ results)
+                                                          const uint32_t *__restrict__ ids, uint32_t count,
+                                                          PageBuffers buf, pq_page_result *results,
+                                                          uint32_t only_marked)
 {
     __shared__ DeltaShared sh;
-    const uint32_t page = ids[blockIdx.x];
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t page = ids[i];
+        // behind delta_wave_kernel only the pages it declined are left to do
+        if (only_marked && results[page].status != kNeedGeneric) continue;
+        const pq_page_desc d = descs[page];
+        const DeltaResult r = delta_stream<UT>(sh, buf.src + d.src_off, (int64_t)d.src_len, d.n_values,
+                                               reinterpret_cast<UT *>(buf.values + d.dst_off));
+        if (threadIdx.x == 0) {
+            pq_page_result out;
+            out.status = r.status;
+            out.stage = PQ_STAGE_NONE;
+            out.detail = 0;
+            out.n_decoded = r.n_decoded;
+            out.not_null = 0;
+            out.n_levels = 0;
+            out.consumed = r.consumed;
+            results[page] = out;
+        }
+        __syncthreads();
+    }
+}
+
+// One wave per page (4 pages per workgroup, no workgroup barrier anywhere).
+template <typename UT>
+__global__ __launch_bounds__(kWG) void delta_wave_kernel(const pq_page_desc *__restrict__ descs,
+                                                         const uint32_t *__restrict__ ids, uint32_t count,
+                                                         PageBuffers buf,
+                                                         pq_page_result *__restrict__ results)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t window[kWG / kWave][kDwChunk / 4 + 4];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const uint32_t slot = blockIdx.x * (kWG / kWave) + (uint32_t)wave;
+    if (slot >= count) return;
+    const uint32_t page = ids[slot];
     const pq_page_desc d = descs[page];
-    const DeltaResult r = delta_stream<UT>(sh, buf.src + d.src_off, (int64_t)d.src_len, d.n_values,
-                                           reinterpret_cast<UT *>(buf.values + d.dst_off));
-    if (threadIdx.x == 0) {
+    const WaveDeltaResult r = delta_wave<UT>(window[wave], buf.src + d.src_off, (int64_t)d.src_len, d.n_values,
+                                             reinterpret_cast<UT *>(buf.values + d.dst_off), lane);
+    if (lane == 0) {
         pq_page_result out;
         out.status = r.status;
         out.stage = PQ_STAGE_NONE;
@@ -460,15 +495,33 @@ hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const
 }
 
 hipError_t launch_delta_pages(hipStream_t s, int bits, const pq_page_desc *d_descs, const uint32_t *d_ids,
-                              uint32_t count, PageBuffers buf, pq_page_result *d_results)
+                              uint32_t count, PageBuffers buf, pq_page_result *d_results,
+                              uint32_t wave_min_pages)
 {
     if (count == 0) return hipSuccess;
+    // Enough pages to fill the chip with one wave each (256 CUs x 8 waves and up): the
+    // barrier-free wave-per-page kernel first, then the workgroup-per-page kernel sweeps
+    // up the pages whose layout is not 128 / 4 (normally none: its workgroups just look
+    // at the status words).  Few, large pages go to the workgroup-per-page kernel directly.
+    const bool wave_first = count >= wave_min_pages;
+    if (wave_first) {
+        const uint32_t grid = (count + kWG / kWave - 1) / (kWG / kWave);
+        if (bits == 64)
+            hipLaunchKernelGGL(delta_wave_kernel<uint64_t>, dim3(grid), dim3(kWG), 0, s, d_descs, d_ids, count,
+                               buf, d_results);
+        else
+            hipLaunchKernelGGL(delta_wave_kernel<uint32_t>, dim3(grid), dim3(kWG), 0, s, d_descs, d_ids, count,
+                               buf, d_results);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    const uint32_t grid = wave_first ? min(count, 512u) : count;
     if (bits == 64)
-        hipLaunchKernelGGL(delta_pages_kernel<uint64_t>, dim3(count), dim3(kWG), 0, s, d_descs, d_ids, buf,
-                           d_results);
+        hipLaunchKernelGGL(delta_pages_kernel<uint64_t>, dim3(grid), dim3(kWG), 0, s, d_descs, d_ids, count, buf,
+                           d_results, wave_first ? 1u : 0u);
     else
-        hipLaunchKernelGGL(delta_pages_kernel<uint32_t>, dim3(count), dim3(kWG), 0, s, d_descs, d_ids, buf,
-                           d_results);
+        hipLaunchKernelGGL(delta_pages_kernel<uint32_t>, dim3(grid), dim3(kWG), 0, s, d_descs, d_ids, count, buf,
+                           d_results, wave_first ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -297,6 +297,19 @@ def _check_delta(c, bits):
         assert r["consumed"] == want["consumed"], (bits, c.n, c.result_src_len)
 
 
+def _run_delta_both_ways(ctx, cases, bits, seed):
+    """Same cases through the one-wave-per-page kernel (which passes other layouts on)
+    and through the workgroup-per-page kernel alone."""
+    try:
+        for min_pages in (0, 1 << 30):
+            ctx.set_option(K.OPT_DELTA_WAVE_MIN_PAGES, min_pages)
+            run_cases(ctx, cases, seed=seed)
+            for c in cases:
+                _check_delta(c, bits)
+    finally:
+        ctx.set_option(K.OPT_DELTA_WAVE_MIN_PAGES, 2048)
+
+
 def test_delta_golden_vectors(ctx, golden_dir):
     d = _load(golden_dir, "delta.json")
     for bits, kind in ((32, K.KIND_DELTA32), (64, K.KIND_DELTA64)):
@@ -344,9 +357,7 @@ def test_delta_random_vs_oracle(ctx, bits):
                     c = Case(kind, stream, pull)
                     c.result_src_len = stream.size
                     cases.append(c)
-    run_cases(ctx, cases, seed=6)
-    for c in cases:
-        _check_delta(c, bits)
+    _run_delta_both_ways(ctx, cases, bits, seed=6)
 
 
 @pytest.mark.parametrize("bits", [32, 64])
@@ -362,9 +373,7 @@ def test_delta_truncated_at_every_byte(ctx, bits):
         c = Case(kind, stream[:cut].copy(), 300)
         c.result_src_len = cut
         cases.append(c)
-    run_cases(ctx, cases, seed=7)
-    for c in cases:
-        _check_delta(c, bits)
+    _run_delta_both_ways(ctx, cases, bits, seed=7)
 
 
 @pytest.mark.parametrize("bits", [32, 64])
@@ -388,9 +397,7 @@ def test_delta_fuzz_headers_and_bodies(ctx, bits):
         c = Case(kind, s, int(rng.integers(0, 800)))
         c.result_src_len = s.size
         cases.append(c)
-    run_cases(ctx, cases, seed=8)
-    for c in cases:
-        _check_delta(c, bits)
+    _run_delta_both_ways(ctx, cases, bits, seed=8)
 
 
 # ---------------------------------------------------------------------------
