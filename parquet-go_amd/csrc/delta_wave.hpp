@@ -5,13 +5,16 @@
 // encoding/delta-binary-packed-decoder.go:29-170,213-225,289-301), organised so that
 // nothing ever waits on another wave: each wave owns a page, a private 3 KiB LDS
 // window and its running value.  Per iteration a wave
-//   1. walks 4 block headers from its LDS window (zig-zag minDelta, 4 width bytes;
-//      wave-uniform arithmetic: prefix of widths by one multiply),
+//   1. walks up to 4 block headers from its LDS window on the SCALAR unit (zig-zag
+//      minDelta, 4 width bytes, prefix of the widths by one multiply),
 //   2. issues the coalesced 16-byte loads of the NEXT window into registers,
-//   3. decodes the 4 blocks: each lane unpacks 2 adjacent deltas with a 96-bit
-//      funnel read, a DPP inclusive scan over the lane sums gives the in-block
-//      prefix, the running value is added and 2 x int64 go out in one 16-byte store,
+//   3. decodes the blocks: each lane unpacks 2 adjacent deltas with a funnel read
+//      of 3 LDS words, a DPP inclusive scan over the lane sums gives the in-block
+//      prefix (32-bit when widths and minDelta allow, else 64-bit), the running
+//      value is added and 2 x int64 go out in one 16-byte store,
 //   4. commits the prefetched registers to LDS.
+// A block that is the page's last, is cut short or has an unusual header goes
+// through wave_walk_slow, which applies every check of the reference's reader.
 // Pages with any other layout are handed to the workgroup-per-page kernel.
 #pragma once
 
@@ -19,8 +22,9 @@
 
 namespace pq {
 
-constexpr int kDwChunk = 3072;  // bytes staged per wave and iteration
-constexpr int kDwTiles = 4;     // blocks decoded per iteration: 15 + 4 * (10 + 4 + 512) <= kDwChunk
+constexpr int kDwChunk = 3072;    // bytes of the stream held in a wave's LDS window
+constexpr int kDwBlockMax = 544;  // >= 10 + 4 + 512 (largest 128-value block), a multiple of 16
+constexpr int kDwStride = kDwChunk - kDwBlockMax; // distance between consecutive windows
 constexpr int kDwPieces = kDwChunk / 16 / kWave; // 16-byte pieces per lane
 constexpr int32_t kNeedGeneric = -2;
 
@@ -32,20 +36,24 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
 struct WavePrefetch {
     uint4 v[kDwPieces];
 };
 
+// Issue the loads of the window [c0, c0 + kDwChunk) and touch none of the results, so
+// that they stay in flight until wave_commit.  Every 16-byte piece that intersects the
+// stream is loaded whole: the few bytes of such a piece that lie before the stream or
+// past its end belong to the same 16-byte line of the caller's buffer, and the decoder
+// never lets them reach a stored value (availability is decided from `len` alone).
 __device__ __forceinline__ void wave_fetch(WavePrefetch &pf, const uint8_t *S, int64_t c0, int64_t len, int lane)
 {
 #pragma unroll
     for (int k = 0; k < kDwPieces; ++k) {
         const int64_t o = c0 + 16 * (int64_t)(lane + kWave * k);
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (o + 16 > 0 && o < len) {
-            v = *reinterpret_cast<const uint4 *>(S + o);
-            if (o < 0 || o + 16 > len) v = mask_piece(v, -o, len - o);
-        }
+        if (o + 16 > 0 && o < len) v = *reinterpret_cast<const uint4 *>(S + o);
         pf.v[k] = v;
     }
 }
@@ -63,7 +71,11 @@ struct WaveTile {
     uint32_t widths;  // 4 miniblock widths, one per byte
     uint32_t prefix;  // byte j = widths[0] + ... + widths[j-1]
     uint64_t min_delta;
+    uint32_t p0;      // position of the block's first value
     uint32_t valid;   // 1 = decode this tile
+    // fast walk only: minDelta is left as its raw varint (first 4 header bytes and the
+    // varint's length, 1..4) for the vector unit to expand; md_raw == 0: min_delta holds it
+    uint32_t md_raw, hdr_lo, vl;
 };
 
 template <typename UT>
@@ -80,9 +92,7 @@ struct WaveState {
     uint32_t last_group;  // index of that group inside its block (0..15)
 };
 
-// Walk one block header at st.pos.  B = LDS window bytes, c0 = its stream offset.
-template <typename UT>
-__device__ __forceinline__ WaveTile wave_walk(WaveState<UT> &st, const uint8_t *B, int64_t c0, int64_t len)
+__device__ __forceinline__ WaveTile wave_tile_none()
 {
     WaveTile t;
     t.valid = 0;
@@ -90,6 +100,20 @@ __device__ __forceinline__ WaveTile wave_walk(WaveState<UT> &st, const uint8_t *
     t.widths = 0;
     t.prefix = 0;
     t.min_delta = 0;
+    t.p0 = 0;
+    t.md_raw = 0;
+    t.hdr_lo = 0;
+    t.vl = 0;
+    return t;
+}
+
+// Walk one block header at st.pos with every check of the reference's reader:
+// taken for a page's last block, for blocks cut short by the end of the stream
+// and for malformed headers.  B = LDS window bytes, c0 = its stream offset.
+template <typename UT>
+__device__ __forceinline__ WaveTile wave_walk_slow(WaveState<UT> &st, const uint8_t *B, int64_t c0, int64_t len)
+{
+    WaveTile t = wave_tile_none();
     if (st.finished) return t;
     const uint32_t p0 = st.tiles_done * 128u;
     if (p0 >= st.need) {
@@ -149,6 +173,7 @@ __device__ __forceinline__ WaveTile wave_walk(WaveState<UT> &st, const uint8_t *
         }
     }
     t.valid = 1;
+    t.p0 = p0;
     t.bitbase = (uint32_t)(pos - c0) * 8u;
     t.widths = wd;
     t.prefix = prefix;
@@ -174,6 +199,42 @@ __device__ __forceinline__ WaveTile wave_walk(WaveState<UT> &st, const uint8_t *
     return t;
 }
 
+// The common case, on the scalar unit and in 32-bit arithmetic relative to the LDS
+// window: a whole block (all 16 groups present in the stream, more values needed
+// after it) whose minDelta varint has at most 4 bytes.  `o` is the window offset of
+// the block header, `lim` the window offset of the end of the stream, p0 the
+// position of the block's first value.  Returns false, changing nothing, whenever
+// any of that does not hold; the caller then takes wave_walk_slow.
+__device__ __forceinline__ bool wave_walk_fast(WaveTile &t, const uint32_t *lds, uint32_t &o, uint32_t lim,
+                                               uint32_t &p0, uint32_t need)
+{
+    if (p0 + 128u >= need) return false; // the page's last block takes the checked path
+    const uint32_t k = o >> 2, s = (o & 3u) * 8u;
+    const uint32_t d0 = uni(lds[k]), d1 = uni(lds[k + 1]), d2 = uni(lds[k + 2]);
+    const uint32_t lo = (uint32_t)(((((uint64_t)d1) << 32) | d0) >> s);  // header bytes 0..3
+    const uint32_t mid = (uint32_t)(((((uint64_t)d2) << 32) | d1) >> s); // header bytes 4..7
+    const uint32_t stop = ~lo & 0x80808080u;                              // first byte without bit 7
+    if (stop == 0u) return false;
+    const uint32_t vl = ((uint32_t)__builtin_ctz(stop) + 1u) >> 3;       // varint length 1..4
+    const uint32_t wd = (uint32_t)(((((uint64_t)mid) << 32) | lo) >> (8u * vl));
+    if ((((wd & 0x7f7f7f7fu) + 0x5f5f5f5fu) | wd) & 0x80808080u) return false; // a width > 32
+    const uint32_t total_w = (wd * 0x01010101u) >> 24;
+    const uint32_t data = o + vl + 4u;
+    const uint32_t next = data + 4u * total_w;
+    if (next > lim) return false;
+    t.valid = 1;
+    t.p0 = p0;
+    t.bitbase = data * 8u;
+    t.widths = wd;
+    t.prefix = wd * 0x01010100u;
+    t.md_raw = 1;
+    t.hdr_lo = lo;
+    t.vl = vl;
+    o = next;
+    p0 += 128u;
+    return true;
+}
+
 // Bytes the reference's reader would have consumed (see delta_consumed in delta_stream.hpp).
 template <typename UT>
 __device__ __forceinline__ uint64_t wave_consumed(const WaveState<UT> &st, int64_t len)
@@ -192,38 +253,86 @@ __device__ __forceinline__ uint64_t wave_consumed(const WaveState<UT> &st, int64
     return (uint64_t)pos;
 }
 
-template <typename UT>
-__device__ __forceinline__ void wave_decode_tile(const uint32_t *lds, const WaveTile &t, UT &carry, UT *dst,
-                                                 uint32_t p0, uint32_t clip, bool vec_ok, int lane)
+// Per-lane constants of the decode.
+struct WaveLane {
+    uint32_t sh8; // 8 * miniblock index of this lane's 2 values
+    uint32_t k2;  // index of the first of them inside the miniblock
+};
+
+// minDelta of a fast-walked block from its raw varint, on the vector unit (the scalar
+// unit is the scarcer resource in this kernel; the asm move keeps the compiler from
+// pulling the uniform arithmetic back onto it).
+__device__ __forceinline__ int32_t wave_expand_min_delta(uint32_t hdr_lo, uint32_t vl)
 {
-    const uint32_t sh8 = (uint32_t)(lane >> 4) * 8u;
-    const uint32_t w = (t.widths >> sh8) & 0xffu;
-    const uint32_t pre = (t.prefix >> sh8) & 0xffu;
-    const uint32_t bit = t.bitbase + pre * 32u + (2u * (uint32_t)(lane & 15)) * w;
-    const uint64_t x = extract64(lds, bit, 2u * w);
-    const uint32_t m = (w >= 32u) ? 0xffffffffu : ((1u << w) - 1u);
-    const UT md = (UT)t.min_delta;
-    const UT a = (UT)((uint32_t)x & m) + md;
-    const UT b = (UT)((uint32_t)(x >> w) & m) + md;
-    const UT pair = a + b;
-    UT incl;
-    if constexpr (sizeof(UT) == 8) incl = wave_scan_u64(pair); else incl = wave_scan_u32(pair);
-    const UT v0 = carry + (incl - pair);
-    const UT v1 = v0 + a;
-    UT tot;
-    if constexpr (sizeof(UT) == 8) tot = wave_last_u64(incl); else tot = wave_last_u32(incl);
-    carry += tot;
-    const uint32_t p = p0 + 2u * (uint32_t)lane;
-    if (p + 1u < clip && vec_ok) {
-        if constexpr (sizeof(UT) == 8)
+    uint32_t v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(hdr_lo));
+    v &= 0xffffffffu >> (32u - 8u * vl);
+    const uint32_t x = (v & 0x7fu) | ((v >> 1) & 0x3f80u) | ((v >> 2) & 0x1fc000u) | ((v >> 3) & 0xfe00000u);
+    return (int32_t)(x >> 1) ^ -(int32_t)(x & 1u);
+}
+
+// CLIPPED = false: a whole block, stored unconditionally.
+template <typename UT, bool CLIPPED>
+__device__ __forceinline__ void wave_decode_tile(const uint32_t *lds, const WaveTile &t, UT &carry, UT *dst,
+                                                 uint32_t clip, bool vec_ok, int lane, WaveLane ln)
+{
+    const uint32_t w = __builtin_amdgcn_ubfe(t.widths, ln.sh8, 8u);
+    const uint32_t pre = __builtin_amdgcn_ubfe(t.prefix, ln.sh8, 8u);
+    const uint32_t bit = t.bitbase + pre * 32u + ln.k2 * w;
+    const uint32_t i = bit >> 5, s = bit & 31u;
+    const uint32_t d0 = lds[i], d1 = lds[i + 1], d2 = lds[i + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, s);
+    const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, s);
+    const uint32_t m = (uint32_t)(1ull << w) - 1u; // w == 32 -> 0xffffffff, w == 0 -> 0
+    const uint32_t ua = lo & m;
+    const uint32_t ub = (uint32_t)((((uint64_t)hi << 32) | lo) >> w) & m;
+    const uint32_t p = t.p0 + 2u * (uint32_t)lane;
+    // every width <= 23 ?
+    const bool thin = (((t.widths & 0x7f7f7f7fu) + 0x68686868u) & 0x80808080u) == 0u;
+    UT v0, v1;
+    if constexpr (sizeof(UT) == 8) {
+        // With every width <= 23 and |minDelta| < 2^22 each delta lies in (-2^22, 1.5 * 2^23),
+        // so all 128 in-block partial sums fit a signed 32-bit integer.  A raw minDelta of
+        // at most 3 varint bytes is below 2^20 in magnitude.
+        const bool narrow = thin && (t.md_raw ? t.vl <= 3u
+                                              : ((int64_t)t.min_delta > -(1ll << 22) && (int64_t)t.min_delta < (1ll << 22)));
+        if (narrow) {
+            const int32_t md = t.md_raw ? wave_expand_min_delta(t.hdr_lo, t.vl) : (int32_t)t.min_delta;
+            const int32_t da = (int32_t)ua + md;
+            const int32_t pair = da + (int32_t)ub + md;
+            const int32_t incl = (int32_t)wave_scan_u32((uint32_t)pair);
+            v0 = carry + (UT)(int64_t)(incl - pair);
+            v1 = v0 + (UT)(int64_t)da;
+            carry += (UT)(int64_t)(int32_t)wave_last_u32((uint32_t)incl);
+        } else {
+            const UT md = t.md_raw ? (UT)(int64_t)wave_expand_min_delta(t.hdr_lo, t.vl) : (UT)t.min_delta;
+            const UT a = (UT)ua + md;
+            const UT pair = a + (UT)ub + md;
+            const UT incl = wave_scan_u64(pair);
+            v0 = carry + (incl - pair);
+            v1 = v0 + a;
+            carry += wave_last_u64(incl);
+        }
+        if ((!CLIPPED || p + 1u < clip) && vec_ok) {
             *reinterpret_cast<uint4 *>(dst + p) = make_uint4((uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1,
                                                              (uint32_t)(v1 >> 32));
-        else
-            *reinterpret_cast<uint2 *>(dst + p) = make_uint2(v0, v1);
+            return;
+        }
     } else {
-        if (p < clip) dst[p] = v0;
-        if (p + 1u < clip) dst[p + 1u] = v1;
+        const UT md = t.md_raw ? (UT)wave_expand_min_delta(t.hdr_lo, t.vl) : (UT)t.min_delta;
+        const UT a = ua + md;
+        const UT pair = a + ub + md;
+        const UT incl = wave_scan_u32(pair);
+        v0 = carry + (incl - pair);
+        v1 = v0 + a;
+        carry += wave_last_u32(incl);
+        if ((!CLIPPED || p + 1u < clip) && vec_ok) {
+            *reinterpret_cast<uint2 *>(dst + p) = make_uint2(v0, v1);
+            return;
+        }
     }
+    if (!CLIPPED || p < clip) dst[p] = v0;
+    if (!CLIPPED || p + 1u < clip) dst[p + 1u] = v1;
 }
 
 struct WaveDeltaResult {
@@ -275,28 +384,33 @@ __device__ __forceinline__ WaveDeltaResult delta_wave(uint32_t *lds, const uint8
             first = (uint64_t)f;
         }
     }
+    // everything parsed from the window is the same in every lane: say so
+    hs = (int)uni((uint32_t)hs);
+    pos = (int64_t)uni((uint32_t)pos);
     if (hs != PQ_OK) {
         res.status = hs;
         res.init_failed = 1;
         res.consumed = (uint64_t)pos;
         return res;
     }
-    if (total == 0) { // every pull is io.EOF (:97-100)
+    const uint32_t total32 = uni((uint32_t)total);
+    if (total32 == 0) { // every pull is io.EOF (:97-100)
         res.status = n > 0 ? PQ_EOF : PQ_OK;
         res.consumed = (uint64_t)pos;
         return res;
     }
-    if (bs != 128u || nm != 4u) {
+    if (uni((uint32_t)bs) != 128u || uni((uint32_t)nm) != 4u) {
         res.status = kNeedGeneric;
         return res;
     }
+    first = ((uint64_t)uni((uint32_t)(first >> 32)) << 32) | uni((uint32_t)first);
 
     WaveState<UT> st;
     st.pos = pos;
     st.end_pos = pos;
     st.tiles_done = 0;
-    st.total = (uint32_t)total;
-    st.need = min(n, (uint32_t)total);
+    st.total = total32;
+    st.need = min(n, total32);
     st.n_ok = 0;
     st.status = PQ_OK;
     st.finished = 0;
@@ -305,44 +419,68 @@ __device__ __forceinline__ WaveDeltaResult delta_wave(uint32_t *lds, const uint8
     st.last_group = 0;
 
     if (st.need == 0) {
-        // Init still reads the first block header eagerly (:198-204, :274-280)
+        // Init still reads the first block header eagerly (:198-204, :274-280); only
+        // its header errors count, and the reader stops right behind the width bytes
         st.need = 1;
-        (void)wave_walk<UT>(st, B, c0, len);
-        res.status = st.init_failed ? st.status : PQ_OK;
-        res.init_failed = st.init_failed;
-        res.consumed = (uint64_t)(st.init_failed ? pos : st.pos - 0);
-        if (!st.init_failed) {
-            // position just past the header and widths: walk advanced past the data too
-            int64_t p2 = pos;
-            uint64_t z;
+        (void)wave_walk_slow<UT>(st, B, c0, len);
+        res.init_failed = uni(st.init_failed);
+        res.status = res.init_failed ? (int)uni((uint32_t)st.status) : PQ_OK;
+        int64_t p2 = pos;
+        uint64_t z;
+        if (!res.init_failed) {
             (void)read_uvarint(B, c0, len, &p2, &z);
-            res.consumed = (uint64_t)(p2 + 4);
+            p2 += 4;
         }
+        res.consumed = (uint64_t)uni((uint32_t)p2);
         return res;
     }
 
+    WaveLane ln;
+    ln.sh8 = (uint32_t)(lane >> 4) * 8u;
+    ln.k2 = 2u * (uint32_t)(lane & 15);
     UT carry = (UT)first;
+    uint32_t o = (uint32_t)(pos - c0); // window offset of the next block header
+    uint32_t p0 = 0;                   // position of that block's first value
     while (true) {
-        const uint32_t base_tile = st.tiles_done;
-        WaveTile tiles[kDwTiles];
-#pragma unroll
-        for (int k = 0; k < kDwTiles; ++k) tiles[k] = wave_walk<UT>(st, B, c0, len);
-        const bool more = !st.finished;
-        int64_t c1 = c0;
-        if (more) {
-            c1 = chunk_base(S, st.pos);
-            wave_fetch(pf, S, c1, len, lane);
+        // The window [c0, c0 + kDwChunk) is in LDS.  Windows advance by a fixed stride
+        // (a block never needs more than kDwBlockMax bytes, so whatever block straddles
+        // the end of this window starts inside the next one): the next window's loads
+        // do not depend on the walk and are issued before it, a whole window ahead.
+        const int64_t c1 = c0 + kDwStride;
+        const bool tail = c0 + kDwChunk >= len; // this window reaches the end of the stream
+        if (!tail) wave_fetch(pf, S, c1, len, lane);
+        const int64_t left = len - c0;
+        const uint32_t lim = left > (int64_t)kDwChunk ? (uint32_t)kDwChunk : (left < 0 ? 0u : (uint32_t)left);
+        while (!st.finished && (tail || o + (uint32_t)kDwBlockMax <= (uint32_t)kDwChunk)) {
+            WaveTile t = wave_tile_none();
+            if (wave_walk_fast(t, lds, o, lim, p0, st.need)) {
+                wave_decode_tile<UT, false>(lds, t, carry, dst, 0xffffffffu, vec_ok, lane, ln);
+                continue;
+            }
+            st.pos = c0 + (int64_t)o;
+            st.tiles_done = p0 >> 7;
+            t = wave_walk_slow<UT>(st, B, c0, len);
+            // values the checked path read back from LDS are uniform too
+            o = uni((uint32_t)(st.pos - c0));
+            p0 = uni(st.tiles_done) * 128u;
+            st.finished = uni(st.finished);
+            st.status = (int32_t)uni((uint32_t)st.status);
+            st.n_ok = uni(st.n_ok);
+            t.valid = uni(t.valid);
+            t.bitbase = uni(t.bitbase);
+            t.widths = uni(t.widths);
+            t.prefix = uni(t.prefix);
+            t.p0 = uni(t.p0);
+            t.min_delta = ((uint64_t)uni((uint32_t)(t.min_delta >> 32)) << 32) | uni((uint32_t)t.min_delta);
+            const uint32_t clip = st.finished ? st.n_ok : 0xffffffffu;
+            if (t.valid) wave_decode_tile<UT, true>(lds, t, carry, dst, clip, vec_ok, lane, ln);
         }
-        const uint32_t clip = st.finished ? st.n_ok : 0xffffffffu;
-#pragma unroll
-        for (int k = 0; k < kDwTiles; ++k)
-            if (tiles[k].valid)
-                wave_decode_tile<UT>(lds, tiles[k], carry, dst, (base_tile + (uint32_t)k) * 128u, clip, vec_ok, lane);
-        if (!more) break;
+        if (st.finished) break;
         wave_sync();
         wave_commit(lds, pf, lane);
         wave_sync();
         c0 = c1;
+        o -= (uint32_t)kDwStride;
     }
 
     res.status = st.status;

@@ -238,7 +238,9 @@ __global__ __launch_bounds__(kWG) void delta_wave_kernel(const pq_page_desc *__r
 {
     __shared__ __attribute__((aligned(16))) uint32_t window[kWG / kWave][kDwChunk / 4 + 4];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
+    // the wave index is the same in all 64 lanes; telling the compiler so keeps the
+    // page descriptor, the stream walk and all loop control on the scalar unit
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t slot = blockIdx.x * (kWG / kWave) + (uint32_t)wave;
     if (slot >= count) return;
     const uint32_t page = ids[slot];
