@@ -314,8 +314,7 @@ __device__ __forceinline__ void wave_decode_tile(const uint32_t *lds, const Wave
             carry += wave_last_u64(incl);
         }
         if ((!CLIPPED || p + 1u < clip) && vec_ok) {
-            *reinterpret_cast<uint4 *>(dst + p) = make_uint4((uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1,
-                                                             (uint32_t)(v1 >> 32));
+            store_nt16(dst + p, (uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32));
             return;
         }
     } else {
@@ -327,7 +326,7 @@ __device__ __forceinline__ void wave_decode_tile(const uint32_t *lds, const Wave
         v1 = v0 + a;
         carry += wave_last_u32(incl);
         if ((!CLIPPED || p + 1u < clip) && vec_ok) {
-            *reinterpret_cast<uint2 *>(dst + p) = make_uint2(v0, v1);
+            store_nt8(dst + p, v0, v1);
             return;
         }
     }

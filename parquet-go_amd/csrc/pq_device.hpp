@@ -60,6 +60,26 @@ __device__ __forceinline__ int64_t chunk_base(const uint8_t *S, int64_t pos)
     return pos - (int64_t)((reinterpret_cast<uintptr_t>(S) + (uint64_t)pos) & 15u);
 }
 
+// ---- streaming stores ---------------------------------------------------------
+// Decoded values are written once and never read back by the kernel: non-temporal
+// stores keep them from displacing the encoded input in L2 (measured on MI355X with
+// the delta kernel's access pattern and no arithmetic: 6.7 TB/s of read + write
+// traffic against 5.1 TB/s with default-policy stores).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void store_nt16(void *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    u32x4_t v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(p));
+}
+
+__device__ __forceinline__ void store_nt8(void *p, uint32_t a, uint32_t b)
+{
+    u32x2_t v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x2_t *>(p));
+}
+
 // ---- bit extraction from the LDS window --------------------------------------
 
 // w-bit field (0 <= w <= 32) starting at bit `bit` of the little-endian LDS image.
