@@ -99,6 +99,20 @@ def cpu_baseline(src, offs, lens, n, seconds=10.0):
                 all_cores_value=round(multi, 4), all_cores=cores)
 
 
+def measured_traffic(args, in_bytes, out_bytes):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter
+    passes (profiles/r01/traffic.json; the counters cannot be read from inside this
+    process).  Only valid for the workload they were collected on."""
+    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if (t.get("pages"), t.get("values_per_page"), t.get("width")) != (args.pages, args.values_per_page, args.width):
+        return None
+    return t.get("hbm_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,12 +238,13 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "delta_pages_kernel<uint64>",
+                "kernel": "pq::delta_wave_kernel<unsigned long>",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": None,
+                "traffic": measured_traffic(args, in_bytes, out_bytes),
+                "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, see profiles/)",
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(k_avg_s * 1e3, 4),
             },

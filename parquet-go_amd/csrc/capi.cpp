@@ -31,12 +31,14 @@ struct pq_plan {
     pq_page_desc *d_descs = nullptr;
     uint32_t *d_ids = nullptr;
     pq_page_result *d_results = nullptr;
+    uint32_t *d_flags = nullptr; // [0], [1]: sweep wake-up words of the two delta element sizes
+    uint32_t epoch = 0;          // bumped every run; a flag word equal to it is "raised"
     // descriptor ids grouped by kernel: [stream | delta32 | delta64 | data pages]
     uint32_t count[4] = {0, 0, 0, 0};
     uint32_t first[4] = {0, 0, 0, 0};
     uint64_t src_need = 0, values_need = 0, levels_need = 0, dict_need = 0;
     uint32_t dict_lds_bytes = 0;
-    bool has_delta = false;
+    bool has_delta_page = false; // some PAGE_V1/V2 descriptor carries delta values
 };
 
 namespace {
@@ -295,9 +297,9 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
         }
         ids[group_of(d.kind)].push_back((uint32_t)i);
         plan->src_need = std::max(plan->src_need, d.src_off + d.src_len);
-        if (d.kind == PQ_KIND_DELTA32 || d.kind == PQ_KIND_DELTA64 ||
-            d.value_kind == PQ_KIND_DELTA32 || d.value_kind == PQ_KIND_DELTA64)
-            plan->has_delta = true;
+        if ((d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2) &&
+            (d.value_kind == PQ_KIND_DELTA32 || d.value_kind == PQ_KIND_DELTA64))
+            plan->has_delta_page = true;
         const uint32_t vs = value_size(d);
         if (vs) plan->values_need = std::max(plan->values_need, d.dst_off + (uint64_t)d.n_values * vs);
         const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
@@ -327,6 +329,8 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
         hipError_t e = hipMalloc((void **)&plan->d_descs, n_pages * sizeof(pq_page_desc));
         if (e == hipSuccess) e = hipMalloc((void **)&plan->d_ids, n_pages * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc((void **)&plan->d_results, n_pages * sizeof(pq_page_result));
+        if (e == hipSuccess) e = hipMalloc((void **)&plan->d_flags, 256);
+        if (e == hipSuccess) e = hipMemset(plan->d_flags, 0, 256);
         // synchronous copies: the host vectors die with this call
         if (e == hipSuccess)
             e = hipMemcpy(plan->d_descs, descs, n_pages * sizeof(pq_page_desc), hipMemcpyHostToDevice);
@@ -351,6 +355,7 @@ void pq_plan_destroy(pq_plan *plan)
     if (plan->d_descs) (void)hipFree(plan->d_descs);
     if (plan->d_ids) (void)hipFree(plan->d_ids);
     if (plan->d_results) (void)hipFree(plan->d_results);
+    if (plan->d_flags) (void)hipFree(plan->d_flags);
     delete plan;
 }
 
@@ -375,15 +380,20 @@ int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_valu
                         (const uint8_t *)d_dict};
     PQ_HIP(ctx, pq::launch_stream_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[0],
                                         plan->count[0], buf, plan->d_results, plan->dict_lds_bytes));
+    plan->epoch += 1;
+    if (plan->epoch == 0) plan->epoch = 1; // 0 is what the flag words start as
+    bool serial32 = false, serial64 = false;
     PQ_HIP(ctx, pq::launch_delta_pages(ctx->stream, 32, plan->d_descs, plan->d_ids + plan->first[1],
-                                       plan->count[1], buf, plan->d_results, ctx->delta_wave_min_pages));
+                                       plan->count[1], buf, plan->d_results, ctx->delta_wave_min_pages,
+                                       plan->d_flags, plan->epoch, &serial32));
     PQ_HIP(ctx, pq::launch_delta_pages(ctx->stream, 64, plan->d_descs, plan->d_ids + plan->first[2],
-                                       plan->count[2], buf, plan->d_results, ctx->delta_wave_min_pages));
+                                       plan->count[2], buf, plan->d_results, ctx->delta_wave_min_pages,
+                                       plan->d_flags + 32, plan->epoch, &serial64));
     PQ_HIP(ctx, pq::launch_data_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[3],
                                       plan->count[3], buf, plan->d_results, plan->dict_lds_bytes));
-    // groups 1..3 are contiguous in d_ids; pages with a delta layout outside the tiled path
-    // (possible only if the plan holds delta descriptors at all) are completed serially
-    if (plan->has_delta)
+    // groups 1..3 are contiguous in d_ids; pages whose delta layout the tiled kernels
+    // declined (and did not finish themselves) are completed one lane per page
+    if (serial32 || serial64 || plan->has_delta_page)
         PQ_HIP(ctx, pq::launch_delta_serial(ctx->stream, plan->d_descs, plan->d_ids + plan->first[1],
                                             plan->count[1] + plan->count[2] + plan->count[3], buf,
                                             plan->d_results));

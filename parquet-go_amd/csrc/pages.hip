@@ -200,21 +200,29 @@ __global__ __launch_bounds__(kWG) void stream_pages_kernel(const pq_page_desc *_
 // page is then finished by delta_serial_kernel, launched right behind.
 constexpr int32_t kNeedSerial = -1;
 
-template <typename UT>
+// SWEEP = false: every descriptor in ids[] is decoded; layouts outside the tiled path
+//                 are left marked kNeedSerial for delta_serial_kernel.
+// SWEEP = true : runs behind delta_wave_kernel and only looks at the pages that kernel
+//                 declined (marked kNeedGeneric); `flag` holds the current `epoch` iff
+//                 there is at least one, so the usual launch ends after one load.  A
+//                 page the tiled path cannot take either is finished here by one lane.
+template <typename UT, bool SWEEP>
 __global__ __launch_bounds__(kWG) void delta_pages_kernel(const pq_page_desc *__restrict__ descs,
                                                           const uint32_t *__restrict__ ids, uint32_t count,
                                                           PageBuffers buf, pq_page_result *results,
-                                                          uint32_t only_marked)
+                                                          const uint32_t *flag, uint32_t epoch)
 {
     __shared__ DeltaShared sh;
+    if (SWEEP && *flag != epoch) return;
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
         const uint32_t page = ids[i];
-        // behind delta_wave_kernel only the pages it declined are left to do
-        if (only_marked && results[page].status != kNeedGeneric) continue;
+        if (SWEEP && results[page].status != kNeedGeneric) continue;
         const pq_page_desc d = descs[page];
-        const DeltaResult r = delta_stream<UT>(sh, buf.src + d.src_off, (int64_t)d.src_len, d.n_values,
-                                               reinterpret_cast<UT *>(buf.values + d.dst_off));
+        const uint8_t *S = buf.src + d.src_off;
+        UT *dst = reinterpret_cast<UT *>(buf.values + d.dst_off);
+        DeltaResult r = delta_stream<UT>(sh, S, (int64_t)d.src_len, d.n_values, dst);
         if (threadIdx.x == 0) {
+            if (SWEEP && r.status == kNeedSerial) r = delta_serial<UT>(S, (int64_t)d.src_len, d.n_values, dst);
             pq_page_result out;
             out.status = r.status;
             out.stage = PQ_STAGE_NONE;
@@ -234,7 +242,8 @@ template <typename UT>
 __global__ __launch_bounds__(kWG) void delta_wave_kernel(const pq_page_desc *__restrict__ descs,
                                                          const uint32_t *__restrict__ ids, uint32_t count,
                                                          PageBuffers buf,
-                                                         pq_page_result *__restrict__ results)
+                                                         pq_page_result *__restrict__ results,
+                                                         uint32_t *flag, uint32_t epoch)
 {
     __shared__ __attribute__((aligned(16))) uint32_t window[kWG / kWave][kDwChunk / 4 + 4];
     const int lane = threadIdx.x & (kWave - 1);
@@ -257,6 +266,7 @@ __global__ __launch_bounds__(kWG) void delta_wave_kernel(const pq_page_desc *__r
         out.n_levels = 0;
         out.consumed = r.consumed;
         results[page] = out;
+        if (r.status == kNeedGeneric) *flag = epoch; // wakes the sweep kernel behind this one
     }
 }
 
@@ -498,32 +508,40 @@ hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const
 
 hipError_t launch_delta_pages(hipStream_t s, int bits, const pq_page_desc *d_descs, const uint32_t *d_ids,
                               uint32_t count, PageBuffers buf, pq_page_result *d_results,
-                              uint32_t wave_min_pages)
+                              uint32_t wave_min_pages, uint32_t *d_flag, uint32_t epoch, bool *needs_serial)
 {
+    *needs_serial = false;
     if (count == 0) return hipSuccess;
     // Enough pages to fill the chip with one wave each (256 CUs x 8 waves and up): the
-    // barrier-free wave-per-page kernel first, then the workgroup-per-page kernel sweeps
-    // up the pages whose layout is not 128 / 4 (normally none: its workgroups just look
-    // at the status words).  Few, large pages go to the workgroup-per-page kernel directly.
-    const bool wave_first = count >= wave_min_pages;
-    if (wave_first) {
+    // barrier-free wave-per-page kernel first, then a sweep by the workgroup-per-page
+    // kernel over the pages whose layout is not 128 / 4 (normally none: it ends after
+    // reading one flag word).  Few, large pages go to the workgroup-per-page kernel directly.
+    if (count >= wave_min_pages) {
         const uint32_t grid = (count + kWG / kWave - 1) / (kWG / kWave);
         if (bits == 64)
             hipLaunchKernelGGL(delta_wave_kernel<uint64_t>, dim3(grid), dim3(kWG), 0, s, d_descs, d_ids, count,
-                               buf, d_results);
+                               buf, d_results, d_flag, epoch);
         else
             hipLaunchKernelGGL(delta_wave_kernel<uint32_t>, dim3(grid), dim3(kWG), 0, s, d_descs, d_ids, count,
-                               buf, d_results);
+                               buf, d_results, d_flag, epoch);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
+        const uint32_t sweep = min(count, 256u);
+        if (bits == 64)
+            hipLaunchKernelGGL((delta_pages_kernel<uint64_t, true>), dim3(sweep), dim3(kWG), 0, s, d_descs, d_ids,
+                               count, buf, d_results, d_flag, epoch);
+        else
+            hipLaunchKernelGGL((delta_pages_kernel<uint32_t, true>), dim3(sweep), dim3(kWG), 0, s, d_descs, d_ids,
+                               count, buf, d_results, d_flag, epoch);
+        return hipGetLastError();
     }
-    const uint32_t grid = wave_first ? min(count, 512u) : count;
+    *needs_serial = true;
     if (bits == 64)
-        hipLaunchKernelGGL(delta_pages_kernel<uint64_t>, dim3(grid), dim3(kWG), 0, s, d_descs, d_ids, count, buf,
-                           d_results, wave_first ? 1u : 0u);
+        hipLaunchKernelGGL((delta_pages_kernel<uint64_t, false>), dim3(count), dim3(kWG), 0, s, d_descs, d_ids,
+                           count, buf, d_results, d_flag, epoch);
     else
-        hipLaunchKernelGGL(delta_pages_kernel<uint32_t>, dim3(grid), dim3(kWG), 0, s, d_descs, d_ids, count, buf,
-                           d_results, wave_first ? 1u : 0u);
+        hipLaunchKernelGGL((delta_pages_kernel<uint32_t, false>), dim3(count), dim3(kWG), 0, s, d_descs, d_ids,
+                           count, buf, d_results, d_flag, epoch);
     return hipGetLastError();
 }
 

@@ -27,10 +27,13 @@ struct PageBuffers {
 hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
                                uint32_t count, PageBuffers buf, pq_page_result *d_results,
                                uint32_t dict_lds_bytes);
-// wave_min_pages: from this many pages on, the one-wave-per-page kernel runs first.
+// wave_min_pages: from this many pages on, the one-wave-per-page kernel runs first and a
+// sweep kernel (woken through *d_flag == epoch) finishes the pages it declined.
+// *needs_serial: launch_delta_serial must follow for these descriptors.
 hipError_t launch_delta_pages(hipStream_t s, int bits, const pq_page_desc *d_descs,
                               const uint32_t *d_ids, uint32_t count, PageBuffers buf,
-                              pq_page_result *d_results, uint32_t wave_min_pages);
+                              pq_page_result *d_results, uint32_t wave_min_pages, uint32_t *d_flag,
+                              uint32_t epoch, bool *needs_serial);
 hipError_t launch_data_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
                              uint32_t count, PageBuffers buf, pq_page_result *d_results,
                              uint32_t dict_lds_bytes);

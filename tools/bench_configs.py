@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the headline bench): the other workload configurations,
+device-resident, HIP-event timed.  Prints one JSON object per configuration.
+
+  C1  INT32 RLE_DICTIONARY, width 12, 4096-entry dictionary   (pages x 20000 values)
+  C1b same with run-heavy keys (geometric runs, mean 32)
+  C3  plain bit-unpack sweep (int32 and int64 widths), 256 MiB encoded per width
+  C4  nested V1 data pages: rep (w=1) + def (w=2) levels + dictionary values
+  C2x INT64 delta at other miniblock widths / INT32 delta
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from parquet_go_amd import capi, synth  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def timed(fn, stream, steps=10, warmup=2):
+    for _ in range(warmup):
+        fn()
+    stream.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    with torch.cuda.stream(stream):
+        evs[0].record()
+        for i in range(steps):
+            fn()
+            evs[i + 1].record()
+    stream.synchronize()
+    return float(np.median([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])) / 1e3
+
+
+def pack_pages(streams):
+    lens = np.array([s.size for s in streams], dtype=np.int64)
+    offs = np.zeros(len(streams), dtype=np.int64)
+    pos = 0
+    for i, ln in enumerate(lens):
+        offs[i] = pos
+        pos += (int(ln) + 15) // 16 * 16
+    src = np.zeros(pos + 16, dtype=np.uint8)
+    for i, s in enumerate(streams):
+        src[offs[i]: offs[i] + lens[i]] = s
+    return src, offs, lens
+
+
+def report(name, in_bytes, out_bytes, t, extra=None):
+    d = {"config": name, "ms": round(t * 1e3, 4), "out_GBps": round(out_bytes / t / 1e9, 1),
+         "alg_GBps": round((in_bytes + out_bytes) / t / 1e9, 1),
+         "frac_of_8TBps": round((in_bytes + out_bytes) / t / 8e12, 4)}
+    if extra:
+        d.update(extra)
+    print(json.dumps(d), flush=True)
+
+
+def runny(rng, n, hi, mean_run):
+    out = np.empty(n, dtype=np.int64)
+    i = 0
+    while i < n:
+        ln = int(rng.geometric(1.0 / mean_run))
+        out[i:i + ln] = rng.integers(0, hi)
+        i += ln
+    return out
+
+
+def bench_dict(ctx, stream, pages, n, run_heavy, label):
+    rng = np.random.default_rng(1)
+    d = synth.splitmix64(0xD1C7, 4096).astype(np.uint32).view(np.int32)
+    streams, keys_all = [], []
+    distinct = min(pages, 200 if run_heavy else pages)
+    for p in range(distinct):
+        keys = runny(rng, n, 4096, 32) if run_heavy else rng.integers(0, 4096, size=n)
+        keys_all.append(keys)
+        streams.append(np.concatenate([[12], synth.hybrid_encode(keys, 12) if run_heavy
+                                       else synth.hybrid_encode_bitpacked(keys, 12)]).astype(np.uint8))
+    while len(streams) < pages:   # run-heavy pages are slow to synthesise: reuse them
+        streams.append(streams[len(streams) % distinct])
+        keys_all.append(keys_all[len(keys_all) % distinct])
+    src, offs, lens = pack_pages(streams)
+    descs = np.zeros(pages, dtype=capi.DESC_DTYPE)
+    descs["kind"] = capi.KIND_DICT
+    descs["src_off"], descs["src_len"], descs["n_values"] = offs, lens, n
+    descs["dst_off"] = np.arange(pages, dtype=np.uint64) * np.uint64(4 * n)
+    descs["elem_size"], descs["dict_len"] = 4, 4096
+    t_src = torch.from_numpy(src).to(DEV)
+    t_dict = torch.from_numpy(d.copy()).to(DEV)
+    t_out = torch.empty(pages * n, dtype=torch.int32, device=DEV)
+    plan = ctx.plan(descs)
+    fn = lambda: plan.run(t_src.data_ptr(), src.size, t_out.data_ptr(), pages * n * 4, 0, 0,
+                          t_dict.data_ptr(), 4096 * 4)
+    t = timed(fn, stream)
+    res = plan.results()
+    assert (res["status"] == 0).all() and (res["n_decoded"] == n).all()
+    got = t_out.cpu().numpy().reshape(pages, n)
+    for p in (0, pages // 2, pages - 1):
+        assert np.array_equal(got[p], d[keys_all[p]])
+    report(label, int(lens.sum()), pages * n * 4, t, {"pages": pages, "values_per_page": n})
+    plan.close()
+
+
+def bench_bitunpack(ctx, stream, bits, widths, enc_bytes):
+    rng = np.random.default_rng(4)
+    src = rng.integers(0, 256, size=enc_bytes + 64, dtype=np.uint8)
+    t_src = torch.from_numpy(src).to(DEV)
+    es = bits // 8
+    for w in widths:
+        ng = min(enc_bytes // w, (2 << 30) // (8 * es))   # cap the output at 2 GiB
+        t_out = torch.empty(ng * 8, dtype=torch.int32 if bits == 32 else torch.int64, device=DEV)
+        fn = lambda: ctx.bitunpack_dev(t_src.data_ptr(), ng * w, w, ng, t_out.data_ptr(), bits)
+        t = timed(fn, stream, steps=6, warmup=1)
+        report("C3 bitunpack%d w=%d" % (bits, w), ng * w, ng * 8 * es, t, {"groups": ng})
+        del t_out
+
+
+def bench_nested(ctx, stream, pages, n):
+    rng = np.random.default_rng(5)
+    d = synth.splitmix64(7, 4096).astype(np.uint32).view(np.int32)
+    streams, nn = [], []
+    distinct = min(pages, 100)
+    for p in range(distinct):
+        rep = (rng.random(n) >= 0.25).astype(np.int64)
+        deff = np.where(rng.random(n) < 0.8, 3, rng.integers(0, 3, size=n))
+        k = int((deff == 3).sum())
+        keys = rng.integers(0, 4096, size=k)
+        page = np.concatenate([synth.length_prefixed(synth.hybrid_encode(rep, 1)),
+                               synth.length_prefixed(synth.hybrid_encode(deff, 2)),
+                               [12], synth.hybrid_encode_bitpacked(keys, 12)]).astype(np.uint8)
+        streams.append(page)
+        nn.append(k)
+    while len(streams) < pages:
+        streams.append(streams[len(streams) % distinct])
+        nn.append(nn[len(nn) % distinct])
+    src, offs, lens = pack_pages(streams)
+    descs = np.zeros(pages, dtype=capi.DESC_DTYPE)
+    descs["kind"] = capi.KIND_PAGE_V1
+    descs["src_off"], descs["src_len"], descs["n_values"] = offs, lens, n
+    descs["max_rep"], descs["max_def"] = 1, 3
+    descs["value_kind"], descs["elem_size"], descs["dict_len"] = capi.KIND_DICT, 4, 4096
+    descs["dst_off"] = np.arange(pages, dtype=np.uint64) * np.uint64(4 * n)
+    descs["rep_off"] = np.arange(pages, dtype=np.uint64) * np.uint64(8 * n)
+    descs["def_off"] = descs["rep_off"] + np.uint64(4 * n)
+    t_src = torch.from_numpy(src).to(DEV)
+    t_dict = torch.from_numpy(d.copy()).to(DEV)
+    t_val = torch.empty(pages * n, dtype=torch.int32, device=DEV)
+    t_lvl = torch.empty(pages * n * 2, dtype=torch.int32, device=DEV)
+    plan = ctx.plan(descs)
+    fn = lambda: plan.run(t_src.data_ptr(), src.size, t_val.data_ptr(), pages * n * 4, t_lvl.data_ptr(),
+                          pages * n * 8, t_dict.data_ptr(), 4096 * 4)
+    t = timed(fn, stream, steps=6, warmup=1)
+    res = plan.results()
+    assert (res["status"] == 0).all(), res[res["status"] != 0][:5]
+    assert (res["not_null"] == np.array(nn)).all()
+    out_bytes = pages * n * 8 + 4 * int(np.sum(nn))
+    report("C4 nested V1 pages (rep w=1, def w=2, dict w=12)", int(lens.sum()), out_bytes, t,
+           {"pages": pages, "slots_per_page": n})
+    plan.close()
+
+
+def bench_delta(ctx, stream, pages, n, bits, width):
+    rng = np.random.default_rng(3)
+    dt = np.int64 if bits == 64 else np.int32
+    streams = []
+    for p in range(pages):
+        steps = rng.integers(0, 1 << width, size=n - 1, dtype=np.int64) - 5
+        v = np.concatenate([[p * 7], p * 7 + np.cumsum(steps)]).astype(dt)
+        streams.append(synth.delta_encode(v, bits))
+    src, offs, lens = pack_pages(streams)
+    descs = np.zeros(pages, dtype=capi.DESC_DTYPE)
+    descs["kind"] = capi.KIND_DELTA64 if bits == 64 else capi.KIND_DELTA32
+    descs["src_off"], descs["src_len"], descs["n_values"] = offs, lens, n
+    es = bits // 8
+    descs["dst_off"] = np.arange(pages, dtype=np.uint64) * np.uint64(es * n)
+    t_src = torch.from_numpy(src).to(DEV)
+    t_out = torch.empty(pages * n * es, dtype=torch.uint8, device=DEV)
+    plan = ctx.plan(descs)
+    fn = lambda: plan.run(t_src.data_ptr(), src.size, t_out.data_ptr(), pages * n * es)
+    t = timed(fn, stream)
+    res = plan.results()
+    assert (res["status"] == 0).all() and (res["n_decoded"] == n).all()
+    report("C2x delta%d width %d" % (bits, width), int(lens.sum()), pages * n * es, t,
+           {"pages": pages, "values_per_page": n})
+    plan.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--pages", type=int, default=2000)
+    args = ap.parse_args()
+    stream = torch.cuda.Stream(device=DEV)
+    ctx = capi.Context(0, stream.cuda_stream)
+    want = lambda k: (not args.only) or k in args.only.split(",")
+    t0 = time.time()
+    if want("c1"):
+        bench_dict(ctx, stream, args.pages, 20000, False, "C1 dict w=12 uniform keys")
+        bench_dict(ctx, stream, 1, 1000000, False, "C1 dict w=12, one 1M-value page")
+    if want("c1b"):
+        bench_dict(ctx, stream, args.pages, 20000, True, "C1b dict w=12 run-heavy keys (mean run 32)")
+    if want("c3"):
+        bench_bitunpack(ctx, stream, 32, [1, 4, 8, 12, 16, 24, 32], 256 << 20)
+        bench_bitunpack(ctx, stream, 64, [8, 16, 33, 48, 64], 256 << 20)
+    if want("c4"):
+        bench_nested(ctx, stream, args.pages, 20000)
+    if want("c2x"):
+        for w in (4, 8, 24, 30):
+            bench_delta(ctx, stream, args.pages, 20000, 64, w)
+        bench_delta(ctx, stream, args.pages, 20000, 32, 12)
+    print("elapsed %.1fs" % (time.time() - t0), file=sys.stderr)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
