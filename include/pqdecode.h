@@ -74,6 +74,9 @@ int pq_ctx_synchronize(pq_ctx *ctx);
  * element size is decoded one wave per page (best when pages outnumber the chip's
  * wave slots); smaller batches use one workgroup per page.  Default 2048. */
 #define PQ_OPT_DELTA_WAVE_MIN_PAGES 1
+/* PQ_OPT_HYBRID_WAVE_MIN_PAGES: the same choice for hybrid / dictionary / level streams and
+ * whole data pages.  Default 1024. */
+#define PQ_OPT_HYBRID_WAVE_MIN_PAGES 2
 int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value);
 const char *pq_status_string(int status);
 const char *pq_last_error(pq_ctx *ctx); /* text of the last HIP failure on ctx */

@@ -21,6 +21,7 @@ struct pq_ctx {
     std::string last_error;
     // grow-only device staging used by the host-pointer entry points
     uint32_t delta_wave_min_pages = 2048; // 256 CUs x 8 waves
+    uint32_t hybrid_wave_min_pages = 1024;
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_cap[4] = {0, 0, 0, 0};
 };
@@ -31,13 +32,16 @@ struct pq_plan {
     pq_page_desc *d_descs = nullptr;
     uint32_t *d_ids = nullptr;
     pq_page_result *d_results = nullptr;
-    uint32_t *d_flags = nullptr; // [0], [1]: sweep wake-up words of the two delta element sizes
+    uint32_t *d_flags = nullptr; // [0], [32], [64]: sweep wake-up words (delta32, delta64, data pages)
     uint32_t epoch = 0;          // bumped every run; a flag word equal to it is "raised"
     // descriptor ids grouped by kernel: [stream | delta32 | delta64 | data pages]
     uint32_t count[4] = {0, 0, 0, 0};
     uint32_t first[4] = {0, 0, 0, 0};
     uint64_t src_need = 0, values_need = 0, levels_need = 0, dict_need = 0;
     uint32_t dict_lds_bytes = 0;
+    // set when every dictionary user reads one and the same dictionary that fits LDS
+    uint32_t shared_dict_bytes = 0;
+    uint64_t shared_dict_off = 0;
     bool has_delta_page = false; // some PAGE_V1/V2 descriptor carries delta values
 };
 
@@ -210,6 +214,10 @@ int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value)
         if (value < 0) return PQ_ERR_BAD_ARGUMENT;
         ctx->delta_wave_min_pages = value > 0xffffffffll ? 0xffffffffu : (uint32_t)value;
         return PQ_OK;
+    case PQ_OPT_HYBRID_WAVE_MIN_PAGES:
+        if (value < 0) return PQ_ERR_BAD_ARGUMENT;
+        ctx->hybrid_wave_min_pages = value > 0xffffffffll ? 0xffffffffu : (uint32_t)value;
+        return PQ_OK;
     default: return PQ_ERR_BAD_ARGUMENT;
     }
 }
@@ -288,6 +296,8 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
     plan->ctx = ctx;
     plan->n = n_pages;
     uint64_t dict_bytes_max = 0;
+    bool dict_seen = false, dict_shared = true;
+    uint64_t dict0_off = 0, dict0_bytes = 0;
     for (size_t i = 0; i < n_pages; ++i) {
         const pq_page_desc &d = descs[i];
         const int st = validate(d);
@@ -310,9 +320,20 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
             const uint64_t db = (uint64_t)d.dict_len * d.elem_size;
             plan->dict_need = std::max(plan->dict_need, d.dict_off + db);
             if (db <= pq::kDictLdsMax) dict_bytes_max = std::max(dict_bytes_max, db);
+            if (!dict_seen) {
+                dict_seen = true;
+                dict0_off = d.dict_off;
+                dict0_bytes = db;
+            } else if (d.dict_off != dict0_off || db != dict0_bytes) {
+                dict_shared = false;
+            }
         }
     }
     plan->dict_lds_bytes = (uint32_t)((dict_bytes_max + 15u) & ~15ull);
+    if (dict_seen && dict_shared && dict0_bytes != 0 && dict0_bytes <= pq::kDictLdsMax) {
+        plan->shared_dict_bytes = (uint32_t)dict0_bytes;
+        plan->shared_dict_off = dict0_off;
+    }
 
     if (hipSetDevice(ctx->device) != hipSuccess) {
         delete plan;
@@ -378,8 +399,9 @@ int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_valu
     PQ_HIP(ctx, hipSetDevice(ctx->device));
     pq::PageBuffers buf{(const uint8_t *)d_src, (uint8_t *)d_values, (uint8_t *)d_levels,
                         (const uint8_t *)d_dict};
+    const pq::WaveLaunch wl{ctx->hybrid_wave_min_pages, plan->shared_dict_bytes, plan->shared_dict_off};
     PQ_HIP(ctx, pq::launch_stream_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[0],
-                                        plan->count[0], buf, plan->d_results, plan->dict_lds_bytes));
+                                        plan->count[0], buf, plan->d_results, plan->dict_lds_bytes, wl));
     plan->epoch += 1;
     if (plan->epoch == 0) plan->epoch = 1; // 0 is what the flag words start as
     bool serial32 = false, serial64 = false;
@@ -390,7 +412,8 @@ int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_valu
                                        plan->count[2], buf, plan->d_results, ctx->delta_wave_min_pages,
                                        plan->d_flags + 32, plan->epoch, &serial64));
     PQ_HIP(ctx, pq::launch_data_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[3],
-                                      plan->count[3], buf, plan->d_results, plan->dict_lds_bytes));
+                                      plan->count[3], buf, plan->d_results, plan->dict_lds_bytes, wl,
+                                      plan->d_flags + 64, plan->epoch));
     // groups 1..3 are contiguous in d_ids; pages whose delta layout the tiled kernels
     // declined (and did not finish themselves) are completed one lane per page
     if (serial32 || serial64 || plan->has_delta_page)

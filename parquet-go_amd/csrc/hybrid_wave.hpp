@@ -1,0 +1,430 @@
+// hybrid_wave.hpp — one WAVE per stream decoder for the RLE / bit-packed hybrid.
+//
+// Same value sequence as hybrid_stream.hpp (reference: HybridDecoder.Next and its
+// helpers, encoding/hybrid-decoder.go:70-170), organised so that a wave never waits on
+// another one: it owns a stream, a private LDS window that advances by a fixed stride
+// (the next window's loads are issued a whole window ahead) and a 64-entry piece table.
+// Per output tile of up to 256 values the wave
+//   1. walks run headers on the SCALAR unit (1..4-byte ULEB128 headers and the RLE value
+//      are taken from three broadcast LDS words with 32-bit arithmetic; anything unusual
+//      goes through a checked byte-wise parse) and records each run, cut at the tile and
+//      window boundaries, as a piece {first position, RLE flag, value | bit address},
+//   2. maps positions to pieces: a piece marks its first position in a 256-byte LDS
+//      array, a DPP prefix sum over the marks numbers the pieces,
+//   3. expands: every lane produces 4 adjacent values (funnel read of two LDS words for
+//      bit-packed pieces), optionally gathers them through a dictionary or counts the
+//      ones equal to the maximum level, and writes 16 or 32 bytes with non-temporal stores.
+#pragma once
+
+#include "delta_wave.hpp"
+#include "hybrid_stream.hpp"
+
+namespace pq {
+
+constexpr int kHwChunk = kDwChunk;              // bytes of the stream in the LDS window
+constexpr int kHwGuard = 64;                    // >= header (10) + RLE value (4) and >= one group (32)
+constexpr int kHwStride = kHwChunk - kHwGuard;  // distance between consecutive windows
+constexpr int kHwTile = 256;                    // values per tile (4 per lane)
+constexpr int kHwSlack = 12;                    // zeroed words behind the window (a last group may hang over)
+
+struct HybridWaveLds {
+    uint32_t window[kHwChunk / 4 + kHwSlack];
+    uint32_t marks[kWave];  // one byte per tile position: 1 = a piece starts here
+    uint2 pieces[kWave];    // x = first position | RLE flag << 31, y = value | bit address
+};
+
+// wave_commit that also zeroes what lies past the end of the stream inside the last
+// 16-byte piece: a short final bit-packed group reads its missing bytes as zero
+// (Read, not ReadFull: encoding/hybrid-decoder.go:138-149).
+__device__ __forceinline__ void wave_commit_clean(uint32_t *lds, const WavePrefetch &pf, int64_t c0, int64_t len,
+                                                  int lane)
+{
+    uint4 *l4 = reinterpret_cast<uint4 *>(lds);
+#pragma unroll
+    for (int k = 0; k < kDwPieces; ++k) {
+        const int64_t o = c0 + 16 * (int64_t)(lane + kWave * k);
+        uint4 v = pf.v[k];
+        if (o < len && o + 16 > len) v = mask_piece(v, 0, len - o);
+        l4[lane + kWave * k] = v;
+    }
+}
+
+// Piece r of the tile under construction, written by the walk (all arguments wave-uniform).
+__device__ __forceinline__ void put_piece(HybridWaveLds &L, uint32_t r, uint32_t sk, uint32_t pl, uint32_t mark_at,
+                                          int lane)
+{
+    if (lane == 0) {
+        L.pieces[r] = make_uint2(sk, pl);
+        reinterpret_cast<uint8_t *>(L.marks)[mark_at] = 1;
+    }
+}
+
+// Wave-uniform state of the walk.
+struct HwState {
+    uint32_t o;       // window offset of the next unparsed byte
+    uint32_t v;       // values produced so far
+    uint32_t pend;    // unfinished run: 0 none, 1 RLE, 2 bit-packed
+    uint32_t pcount;  // RLE: repeats left; bit-packed: groups left
+    uint32_t pvalue;  // RLE value
+    int32_t status;
+};
+
+// Checked parse of the run header at window offset st.o: readRunHeader and
+// readRLERunValue (encoding/hybrid-decoder.go:111-136,151-170) with every error of the
+// reference.  B = window bytes, lim = window offset of the end of the stream.
+__device__ __forceinline__ void hw_header_slow(HwState &st, const uint8_t *B, uint32_t lim, uint32_t w)
+{
+    int64_t pos = (int64_t)st.o;
+    uint32_t pend = 0, pc = 0, pv = 0;
+    int status = PQ_OK;
+    if (st.o >= lim) {
+        status = PQ_EOF;
+    } else {
+        uint64_t h64 = 0;
+        status = read_uvarint(B, 0, (int64_t)lim, &pos, &h64);
+        if (status == PQ_OK && h64 > 0x7fffffffull) status = PQ_INT32_OUT_OF_RANGE;
+        if (status == PQ_OK) {
+            const uint32_t h = (uint32_t)h64;
+            pc = h >> 1;
+            if (h & 1u) {
+                if (pc == 0) status = PQ_EMPTY_BP_RUN; else pend = 2;
+            } else if (pc == 0) {
+                status = PQ_EMPTY_RLE_RUN;
+            } else {
+                const uint32_t vb = (w + 7u) >> 3;
+                const int64_t rem = (int64_t)lim - pos;
+                if (rem <= 0) {
+                    status = PQ_EOF;
+                } else if (rem < (int64_t)vb) {
+                    status = PQ_UNEXPECTED_EOF;
+                    pos = (int64_t)lim;
+                } else {
+                    for (uint32_t k = 0; k < vb; ++k) pv |= (uint32_t)B[pos + k] << (8u * k);
+                    pos += vb;
+                    if (w < 32u && (pv >> w) != 0u) status = PQ_RLE_VALUE_TOO_LARGE; else pend = 1;
+                }
+            }
+        }
+    }
+    // everything read back from LDS is the same in all lanes: say so
+    st.o = uni((uint32_t)pos);
+    st.pend = uni(pend);
+    st.pcount = uni(pend ? pc : 0u);
+    st.pvalue = uni(pv);
+    st.status = (int32_t)uni((uint32_t)status);
+}
+
+// The common headers on the scalar unit: a 1..4-byte varint, a non-empty run, and for RLE a
+// value that fits w bits, all inside the stream.  Returns false, changing nothing, otherwise.
+__device__ __forceinline__ bool hw_header_fast(HwState &st, const uint32_t *lds, uint32_t lim, uint32_t w)
+{
+    const uint32_t o = st.o;
+    const uint32_t k = o >> 2, s = (o & 3u) * 8u;
+    const uint32_t d0 = uni(lds[k]), d1 = uni(lds[k + 1]), d2 = uni(lds[k + 2]);
+    const uint32_t lo = (uint32_t)(((((uint64_t)d1) << 32) | d0) >> s);   // bytes 0..3 at o
+    const uint32_t mid = (uint32_t)(((((uint64_t)d2) << 32) | d1) >> s);  // bytes 4..7
+    const uint32_t stop = ~lo & 0x80808080u;
+    if (stop == 0u) return false;
+    const uint32_t vl = ((uint32_t)__builtin_ctz(stop) + 1u) >> 3;  // varint length 1..4
+    const uint32_t x = lo & (0xffffffffu >> (32u - 8u * vl));
+    const uint32_t h = (x & 0x7fu) | ((x >> 1) & 0x3f80u) | ((x >> 2) & 0x1fc000u) | ((x >> 3) & 0xfe00000u);
+    const uint32_t pc = h >> 1;
+    if (pc == 0u) return false;
+    if (h & 1u) {
+        if (o + vl > lim) return false;
+        st.pend = 2;
+        st.pcount = pc;
+        st.o = o + vl;
+        return true;
+    }
+    const uint32_t vb = (w + 7u) >> 3;  // 1..4 (w == 0 never gets here)
+    if (o + vl + vb > lim) return false;
+    const uint32_t raw = (uint32_t)(((((uint64_t)mid) << 32) | lo) >> (8u * vl));
+    const uint32_t val = raw & (0xffffffffu >> (32u - 8u * vb));
+    if (w < 32u && (val >> w) != 0u) return false;
+    st.pend = 1;
+    st.pcount = pc;
+    st.pvalue = val;
+    st.o = o + vl + vb;
+    return true;
+}
+
+// Per-stream constants of the span parse.
+struct HwConst {
+    uint32_t w;
+    uint32_t vb;      // bytes of an RLE value
+    uint32_t vbmask;  // their mask
+    uint32_t wmask;   // 2^w - 1
+};
+
+// Span parse: all 64 lanes parse a candidate run header at window offsets o .. o + 63 at once;
+// the chain of real headers is then followed from lane 0 with one v_readlane per run.  Only
+// complete, well-formed runs with a one-byte header that lie wholly inside [0, wl) qualify;
+// the chain stops at the first one that does not.  Of the chain, the leading runs that fit
+// `room` values (and the piece table) are appended to the tile under construction: each of
+// their lanes writes its own piece record and start mark.  Returns the number of runs taken;
+// *taken_values and *o_next (offset of the first header not taken) are set when it is not 0.
+__device__ __forceinline__ uint32_t hw_span(HybridWaveLds &L, uint32_t o, uint32_t wl, const HwConst &hc, uint32_t room,
+                                            uint32_t np, uint32_t fill, uint32_t phase, int lane,
+                                            uint32_t *taken_values, uint32_t *o_next)
+{
+    const uint32_t p = o + (uint32_t)lane;
+    const uint32_t i = p >> 2, sh = (p & 3u) * 8u;
+    const uint32_t d0 = L.window[i], d1 = L.window[i + 1], d2 = L.window[i + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh);  // bytes p .. p+3
+    const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, sh);  // bytes p+4 .. p+7
+    const uint32_t val = __builtin_amdgcn_alignbit(hi, lo, 8u) & hc.vbmask;
+    const uint32_t b0 = lo & 0xffu;
+    const uint32_t cnt = b0 >> 1;
+    const bool isbp = (b0 & 1u) != 0u;
+    const uint32_t nbytes = isbp ? 1u + cnt * hc.w : 1u + hc.vb;
+    const uint32_t nvals = isbp ? cnt * 8u : cnt;
+    const bool ok = b0 < 0x80u && cnt != 0u && p + nbytes <= wl && (isbp || (val & ~hc.wmask) == 0u);
+    const uint32_t nextlane = (uint32_t)lane + nbytes;
+    const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
+
+    uint32_t cur = 0;
+    uint64_t chain = 0;
+    do {
+        if (((okmask >> cur) & 1ull) == 0ull) break;
+        chain |= 1ull << cur;
+        cur = (uint32_t)__builtin_amdgcn_readlane((int)nextlane, (int)cur);
+    } while (cur < (uint32_t)kWave);
+    if (chain == 0ull) return 0;
+
+    const bool on = ((chain >> lane) & 1ull) != 0ull;
+    const uint32_t incl = wave_scan_u32(on ? nvals : 0u);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chain >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chain, 0u));
+    const bool take = on && incl <= room && np + rank < (uint32_t)kWave;
+    const uint64_t tmask = __builtin_amdgcn_ballot_w64(take);
+    if (tmask == 0ull) return 0;
+    const uint32_t last = 63u - (uint32_t)__builtin_clzll(tmask);
+    *taken_values = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)last);
+    const uint64_t untaken = chain & ~tmask;
+    *o_next = o + (untaken != 0ull ? (uint32_t)__builtin_ctzll(untaken) : cur);
+    if (take) {
+        const uint32_t start = fill + incl - nvals;
+        L.pieces[np + rank] = make_uint2(isbp ? start : (start | 0x80000000u), isbp ? (p + 1u) * 8u : val);
+        reinterpret_cast<uint8_t *>(L.marks)[phase + start] = 1;
+    }
+    return (uint32_t)__builtin_popcountll(tmask);
+}
+
+template <typename OutT>
+__device__ __forceinline__ void hw_store4(OutT *p, const OutT *out, uint32_t valid, bool vec_ok)
+{
+    if (valid == 0xfu && vec_ok) {
+        if constexpr (sizeof(OutT) == 4) {
+            store_nt16(p, out[0], out[1], out[2], out[3]);
+        } else {
+            store_nt16(p, (uint32_t)out[0], (uint32_t)(out[0] >> 32), (uint32_t)out[1], (uint32_t)(out[1] >> 32));
+            store_nt16(p + 2, (uint32_t)out[2], (uint32_t)(out[2] >> 32), (uint32_t)out[3], (uint32_t)(out[3] >> 32));
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (valid & (1u << k)) p[k] = out[k];
+}
+
+// Decode n values of the stream [S, S + len) at bit width w into dst with ONE wave.
+// Modes as in hybrid_stream.  `dict` may point to LDS or global memory.
+template <int MODE, typename OutT>
+__device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint8_t *S, int64_t len, uint32_t w,
+                                                    uint32_t n, OutT *dst, const OutT *dict, uint32_t dict_len,
+                                                    uint32_t max_level, int lane)
+{
+    HybridResult res{PQ_OK, 0, 0, 0};
+    const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(dst) / sizeof(OutT)) & 3u);
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & (sizeof(OutT) - 1)) == 0;
+
+    if (w == 0) {
+        // bitWidth == 0: Next() yields 0 forever and never touches the reader (hybrid-decoder.go:74-76)
+        OutT zv = 0;
+        bool bad = false;
+        if (MODE == HY_DICT) {
+            if (dict_len == 0) bad = true; else zv = dict[0];
+        }
+        if (!bad)
+            for (uint32_t i = (uint32_t)lane; i < n; i += kWave) dst[i] = zv;
+        res.status = bad && n > 0 ? PQ_DICT_INVALID_INDEX : PQ_OK;
+        res.n_decoded = bad ? 0 : n;
+        res.count_max = (MODE == HY_LEVELS && max_level == 0) ? n : 0;
+        return res;
+    }
+
+    const uint8_t *B = reinterpret_cast<const uint8_t *>(L.window);
+    WavePrefetch pf;
+    int64_t c0 = chunk_base(S, 0);
+    wave_fetch(pf, S, c0, len, lane);
+    if (lane < kHwSlack) L.window[kHwChunk / 4 + lane] = 0;
+    L.marks[lane] = 0;
+    wave_commit_clean(L.window, pf, c0, len, lane);
+    wave_sync();
+
+    HwState st;
+    st.o = (uint32_t)(0 - c0);
+    st.v = 0;
+    st.pend = 0;
+    st.pcount = 0;
+    st.pvalue = 0;
+    st.status = PQ_OK;
+
+    HwConst hc;
+    hc.w = w;
+    hc.vb = (w + 7u) >> 3;
+    hc.vbmask = 0xffffffffu >> (32u - 8u * hc.vb);
+    hc.wmask = w >= 32u ? 0xffffffffu : (1u << w) - 1u;
+
+    uint32_t local_count = 0;  // LEVELS: values equal to max_level seen by this lane
+    bool bad_index = false;    // DICT: a key outside the dictionary seen by this lane
+
+    while (true) {
+        const int64_t c1 = c0 + kHwStride;
+        const bool tail = c0 + kHwChunk >= len;  // this window reaches the end of the stream
+        if (!tail) wave_fetch(pf, S, c1, len, lane);
+        const int64_t left = len - c0;
+        const uint32_t lim = left > (int64_t)(1 << 30) ? (1u << 30) : (left < 0 ? 0u : (uint32_t)left);
+        const uint32_t wl = min(lim, (uint32_t)kHwChunk);  // valid stream bytes in the window
+        bool done = false;
+
+        // ---- tiles decodable from this window ----
+        while (true) {
+            const uint32_t phase = (st.v + mis) & 3u;
+            const uint32_t cap = (uint32_t)kHwTile - phase;
+            uint32_t fill = 0, np = 0;
+            bool want_window = false;
+            while (fill < cap && np < (uint32_t)kWave && st.v + fill < n) {
+                const bool in_window = tail || st.o + (uint32_t)kHwGuard <= (uint32_t)kHwChunk;
+                if (st.pend == 0) {
+                    if (!in_window) { want_window = true; break; }
+                    // peek at the header byte: short runs with one-byte headers go through the
+                    // span parse, 64 candidate positions at a time
+                    const uint32_t b0 = (uni(L.window[st.o >> 2]) >> ((st.o & 3u) * 8u)) & 0xffu;
+                    const bool long_bp = (b0 & 0x81u) == 1u && b0 >= 17u;  // 8 groups and more
+                    const uint32_t room = min(cap - fill, n - st.v - fill);
+                    if (b0 < 0x80u && !long_bp && st.o < wl) {
+                        uint32_t got = 0, o_next = 0;
+                        const uint32_t taken = hw_span(L, st.o, wl, hc, room, np, fill, phase, lane, &got, &o_next);
+                        if (taken != 0u) {
+                            np += taken;
+                            fill += got;
+                            st.o = o_next;
+                            continue;
+                        }
+                        // the first run is malformed, cut short or does not fit: in a tile that is
+                        // already half full leave it to the next one, else take it apart below
+                        if (2u * fill >= cap) break;
+                    } else if (long_bp && 8u * (b0 >> 1) > room && 2u * fill >= cap) {
+                        break;
+                    }
+                    if (!hw_header_fast(st, L.window, lim, w)) {
+                        hw_header_slow(st, B, lim, w);
+                        if (st.status != PQ_OK) break;
+                    }
+                }
+                if (st.pend == 1) {
+                    const uint32_t take = min(st.pcount, min(cap - fill, n - st.v - fill));
+                    put_piece(L, np, fill | 0x80000000u, st.pvalue, fill + phase, lane);
+                    ++np;
+                    fill += take;
+                    st.pcount -= take;
+                    if (st.pcount == 0) st.pend = 0;
+                } else {
+                    // readBitPackedRun (hybrid-decoder.go:138-149): a group is readable while at
+                    // least one byte is left; pieces are whole groups that lie inside the window
+                    if (!in_window) { want_window = true; break; }
+                    uint32_t g = min(st.pcount, min((cap - fill) >> 3, (n - st.v - fill + 7u) >> 3));
+                    if (g == 0) break;  // fewer than 8 positions left in the tile
+                    if (st.o + g * w > min(lim, (uint32_t)kHwChunk)) {
+                        if (st.o >= lim) { st.status = PQ_EOF; break; }
+                        const uint32_t feed = (lim - st.o + w - 1u) / w;          // groups the stream can feed
+                        const uint32_t fit = tail ? feed : ((uint32_t)kHwChunk - st.o) / w;
+                        g = min(g, min(feed, fit));
+                        if (g == 0) { want_window = true; break; }
+                    }
+                    put_piece(L, np, fill, st.o * 8u, fill + phase, lane);
+                    ++np;
+                    fill += 8u * g;
+                    st.o += g * w;
+                    st.pcount -= g;
+                    if (st.pcount == 0) st.pend = 0;
+                }
+            }
+
+            // ---- expand the tile ----
+            const uint32_t clip = min(fill, n - st.v);  // a last group may carry values beyond n
+            if (clip != 0) {
+                uint32_t x = 0, excl = 0;
+                wave_sync();
+                const uint2 rec0 = L.pieces[0];
+                if (np > 1) {
+                    x = L.marks[lane];
+                    x += x << 8;
+                    x += x << 16;  // byte k = pieces started at or before position k of this quad
+                    const uint32_t tot = x >> 24;
+                    excl = wave_scan_u32(tot) - tot;
+                }
+                OutT out[4];
+                uint32_t valid = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t j = 4u * (uint32_t)lane + (uint32_t)k - phase;  // position in the tile
+                    const bool ok = j < clip;                                        // also false for j "negative"
+                    uint32_t sk = rec0.x, pl = rec0.y;
+                    if (np > 1) {
+                        const uint32_t id = (excl + ((x >> (8 * k)) & 0xffu) - 1u) & (uint32_t)(kWave - 1);
+                        const uint2 rec = L.pieces[id];
+                        sk = rec.x;
+                        pl = rec.y;
+                    }
+                    const bool rle = (sk & 0x80000000u) != 0u;
+                    const uint32_t rel = ok ? j - (sk & 0xffffu) : 0u;
+                    const uint32_t bit = rle ? 0u : pl + rel * w;
+                    uint32_t key = extract32(L.window, ok ? bit : 0u, w);
+                    if (rle) key = pl;
+                    out[k] = 0;
+                    if (ok) {
+                        valid |= 1u << k;
+                        if (MODE == HY_DICT) {
+                            if (key < dict_len) out[k] = dict[key]; else bad_index = true;
+                        } else {
+                            out[k] = (OutT)key;
+                            if (MODE == HY_LEVELS && key == max_level) ++local_count;
+                        }
+                    }
+                }
+                // the quad of lane l starts at dst + v - phase + 4l, 4 elements aligned
+                hw_store4<OutT>(dst + ((int64_t)st.v - (int64_t)phase + 4 * (int64_t)lane), out, valid, vec_ok);
+            }
+            if (np != 0) {
+                wave_sync();  // the marks were read; the next walk sets its own
+                L.marks[lane] = 0;
+                wave_sync();
+            }
+            st.v += clip;
+            if (st.status != PQ_OK || st.v >= n) { done = true; break; }
+            if (want_window) break;
+        }
+        if (done) break;
+        wave_sync();
+        wave_commit_clean(L.window, pf, c1, len, lane);
+        wave_sync();
+        c0 = c1;
+        st.o -= (uint32_t)kHwStride;
+    }
+
+    if (MODE == HY_LEVELS) res.count_max = wave_sum_u32(local_count);
+    res.status = st.status;
+    res.n_decoded = st.v;
+    const int64_t pos = c0 + (int64_t)st.o;
+    res.consumed = (uint64_t)min(pos, len);
+    if (MODE == HY_DICT && __builtin_amdgcn_ballot_w64(bad_index) != 0ull) {
+        // DictDecoder.DecodeValues returns (0, "invalid index") (types/dict.go:104-111)
+        res.status = PQ_DICT_INVALID_INDEX;
+        res.n_decoded = 0;
+    }
+    return res;
+}
+
+}  // namespace pq

@@ -12,6 +12,7 @@
 #include "delta_stream.hpp"
 #include "delta_wave.hpp"
 #include "hybrid_stream.hpp"
+#include "hybrid_wave.hpp"
 #include "pq_launch.hpp"
 
 namespace pq {
@@ -296,16 +297,10 @@ __device__ __forceinline__ void finish_page(pq_page_result &out, int32_t v_init,
     }
 }
 
-__global__ __launch_bounds__(kWG) void data_pages_kernel(const pq_page_desc *__restrict__ descs,
-                                                         const uint32_t *__restrict__ ids,
-                                                         PageBuffers buf,
-                                                         pq_page_result *__restrict__ results,
-                                                         uint32_t dict_lds_bytes)
+// One data page by one workgroup.
+__device__ __forceinline__ void data_page_wg(PageShared &sh, uint32_t *ldict, const pq_page_desc &d, uint32_t page,
+                                             PageBuffers buf, pq_page_result *results, uint32_t dict_lds_bytes)
 {
-    PageShared &sh = *reinterpret_cast<PageShared *>(pq_smem);
-    uint32_t *ldict = reinterpret_cast<uint32_t *>(pq_smem + align16(sizeof(PageShared)));
-    const uint32_t page = ids[blockIdx.x];
-    const pq_page_desc d = descs[page];
     const uint8_t *S = buf.src + d.src_off;
     const int64_t len = (int64_t)d.src_len;
     const uint32_t size = d.n_values;
@@ -446,6 +441,311 @@ __global__ __launch_bounds__(kWG) void data_pages_kernel(const pq_page_desc *__r
     if (threadIdx.x == 0) results[page] = out;
 }
 
+// SWEEP = false: one workgroup per descriptor in ids[].
+// SWEEP = true : runs behind data_wave_kernel and redoes only the pages that kernel declined
+//                 (marked kNeedGeneric); `flag` holds the current `epoch` iff there is one.
+template <bool SWEEP>
+__global__ __launch_bounds__(kWG) void data_pages_kernel(const pq_page_desc *__restrict__ descs,
+                                                         const uint32_t *__restrict__ ids, uint32_t count,
+                                                         PageBuffers buf, pq_page_result *results,
+                                                         uint32_t dict_lds_bytes, const uint32_t *flag,
+                                                         uint32_t epoch)
+{
+    PageShared &sh = *reinterpret_cast<PageShared *>(pq_smem);
+    uint32_t *ldict = reinterpret_cast<uint32_t *>(pq_smem + align16(sizeof(PageShared)));
+    if (SWEEP && *flag != epoch) return;
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t page = ids[i];
+        if (SWEEP && results[page].status != kNeedGeneric) continue;
+        const pq_page_desc d = descs[page];
+        data_page_wg(sh, ldict, d, page, buf, results, dict_lds_bytes);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// One WAVE per descriptor: 4 descriptors per workgroup, no barrier after the optional
+// dictionary load.  dict_lds_bytes != 0 promises that every dictionary user of the launch
+// reads the same dictionary, dict_lds_bytes long at buf.dict + dict_lds_off.
+
+struct WaveDict {
+    const uint8_t *g;  // the page's dictionary in global memory
+    const uint32_t *l; // the workgroup's LDS copy, or nullptr
+};
+
+__device__ __forceinline__ const uint32_t *load_wave_dict(uint8_t *smem_after, PageBuffers buf, uint32_t dict_lds_bytes,
+                                                           uint64_t dict_lds_off)
+{
+    if (dict_lds_bytes == 0) return nullptr;
+    uint32_t *ldict = reinterpret_cast<uint32_t *>(smem_after);
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(buf.dict + dict_lds_off);
+    for (uint32_t i = threadIdx.x; i < dict_lds_bytes / 4u; i += kWG) ldict[i] = g[i];
+    __syncthreads();
+    return ldict;
+}
+
+template <int MODE, typename OutT>
+__device__ __forceinline__ HybridResult run_section_wave(HybridWaveLds &L, const Section &sec, uint32_t w, uint32_t n,
+                                                         OutT *dst, const OutT *dict, uint32_t dict_len,
+                                                         uint32_t max_level, int lane)
+{
+    if (sec.no_reader && w != 0) {
+        HybridResult r{n > 0 ? PQ_NOT_INITIALIZED : PQ_OK, 0, 0, 0};
+        return r;
+    }
+    return hybrid_wave<MODE, OutT>(L, sec.S, sec.len, w, n, dst, dict, dict_len, max_level, lane);
+}
+
+__device__ __forceinline__ HybridResult const_levels_wave(uint32_t *dst, uint32_t n, uint32_t max_level, int lane)
+{
+    for (uint32_t i = (uint32_t)lane; i < n; i += kWave) dst[i] = 0;
+    HybridResult r{PQ_OK, n, max_level == 0 ? n : 0u, 0};
+    return r;
+}
+
+template <typename OutT>
+__device__ __forceinline__ HybridResult dict_values_wave(HybridWaveLds &L, const uint8_t *S, int64_t len, uint32_t n,
+                                                         OutT *dst, WaveDict dict, uint32_t dict_len,
+                                                         int32_t *init_status, int lane)
+{
+    HybridResult r{PQ_OK, 0, 0, 0};
+    if (len <= 0) {
+        *init_status = PQ_EOF;
+        r.status = PQ_EOF;
+        return r;
+    }
+    const uint32_t w = uni((uint32_t)S[0]);
+    if (w > 32u) {
+        *init_status = PQ_DICT_INVALID_WIDTH;
+        r.status = PQ_DICT_INVALID_WIDTH;
+        r.consumed = 1;
+        return r;
+    }
+    *init_status = PQ_OK;
+    if (dict.l)
+        r = hybrid_wave<HY_DICT, OutT>(L, S + 1, len - 1, w, n, dst, reinterpret_cast<const OutT *>(dict.l), dict_len,
+                                       0, lane);
+    else
+        r = hybrid_wave<HY_DICT, OutT>(L, S + 1, len - 1, w, n, dst, reinterpret_cast<const OutT *>(dict.g), dict_len,
+                                       0, lane);
+    r.consumed += 1;
+    return r;
+}
+
+__global__ __launch_bounds__(kWG) void stream_wave_kernel(const pq_page_desc *__restrict__ descs,
+                                                          const uint32_t *__restrict__ ids, uint32_t count,
+                                                          PageBuffers buf, pq_page_result *__restrict__ results,
+                                                          uint32_t dict_lds_bytes, uint64_t dict_lds_off)
+{
+    HybridWaveLds *LW = reinterpret_cast<HybridWaveLds *>(pq_smem);
+    const uint32_t *ldict = load_wave_dict(pq_smem + align16((uint32_t)sizeof(HybridWaveLds) * (kWG / kWave)), buf,
+                                           dict_lds_bytes, dict_lds_off);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t slot = blockIdx.x * (kWG / kWave) + (uint32_t)wave;
+    if (slot >= count) return;
+    HybridWaveLds &L = LW[wave];
+    const uint32_t page = ids[slot];
+    const pq_page_desc d = descs[page];
+    const uint8_t *S = buf.src + d.src_off;
+    const int64_t len = (int64_t)d.src_len;
+    const uint32_t n = d.n_values;
+
+    HybridResult r{PQ_OK, 0, 0, 0};
+    if (d.kind == PQ_KIND_HYBRID || d.kind == PQ_KIND_LEVELS) {
+        const bool levels = d.kind == PQ_KIND_LEVELS;
+        const uint32_t w = levels ? bits_len16(d.max_def) : d.bit_width;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(levels ? buf.levels + d.def_off : buf.values + d.dst_off);
+        if (levels && (d.flags & PQ_FLAG_LEVELS_CONST)) {
+            r = const_levels_wave(dst, n, d.max_def, lane);
+        } else {
+            Section sec{S, len, PQ_OK, 0, (d.flags & PQ_FLAG_NO_INIT) != 0};
+            if (d.flags & PQ_FLAG_LENGTH_PREFIXED) sec = section_init_size(S, len, w);
+            if (sec.init_status != PQ_OK) {
+                r.status = sec.init_status;
+            } else if (levels) {
+                r = run_section_wave<HY_LEVELS, uint32_t>(L, sec, w, n, dst, nullptr, 0, d.max_def, lane);
+                if (r.status != PQ_OK) { r.n_decoded = 0; r.count_max = 0; }
+            } else {
+                r = run_section_wave<HY_RAW, uint32_t>(L, sec, w, n, dst, nullptr, 0, 0, lane);
+            }
+            if (d.flags & PQ_FLAG_LENGTH_PREFIXED)
+                r.consumed = sec.consumed_by_init;
+            else if (levels && !sec.no_reader)
+                r.consumed = (uint64_t)len;
+        }
+    } else { // PQ_KIND_DICT
+        WaveDict wd{buf.dict + d.dict_off, ldict};
+        int32_t init_status;
+        if (d.elem_size == 8)
+            r = dict_values_wave<uint64_t>(L, S, len, n, reinterpret_cast<uint64_t *>(buf.values + d.dst_off), wd,
+                                           d.dict_len, &init_status, lane);
+        else
+            r = dict_values_wave<uint32_t>(L, S, len, n, reinterpret_cast<uint32_t *>(buf.values + d.dst_off), wd,
+                                           d.dict_len, &init_status, lane);
+        (void)init_status;
+    }
+    if (lane == 0) {
+        pq_page_result out;
+        out.status = r.status;
+        out.stage = PQ_STAGE_NONE;
+        out.detail = 0;
+        out.n_decoded = r.n_decoded;
+        out.not_null = r.count_max;
+        out.n_levels = 0;
+        out.consumed = r.consumed;
+        results[page] = out;
+    }
+}
+
+// A whole V1 / V2 data page by one wave: same order and error precedence as data_page_wg.
+__global__ __launch_bounds__(kWG) void data_wave_kernel(const pq_page_desc *__restrict__ descs,
+                                                        const uint32_t *__restrict__ ids, uint32_t count,
+                                                        PageBuffers buf, pq_page_result *__restrict__ results,
+                                                        uint32_t dict_lds_bytes, uint64_t dict_lds_off,
+                                                        uint32_t *flag, uint32_t epoch)
+{
+    HybridWaveLds *LW = reinterpret_cast<HybridWaveLds *>(pq_smem);
+    const uint32_t *ldict = load_wave_dict(pq_smem + align16((uint32_t)sizeof(HybridWaveLds) * (kWG / kWave)), buf,
+                                           dict_lds_bytes, dict_lds_off);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t slot = blockIdx.x * (kWG / kWave) + (uint32_t)wave;
+    if (slot >= count) return;
+    HybridWaveLds &L = LW[wave];
+    const uint32_t page = ids[slot];
+    const pq_page_desc d = descs[page];
+    const uint8_t *S = buf.src + d.src_off;
+    const int64_t len = (int64_t)d.src_len;
+    const uint32_t size = d.n_values;
+    uint32_t *rep_dst = reinterpret_cast<uint32_t *>(buf.levels + d.rep_off);
+    uint32_t *def_dst = reinterpret_cast<uint32_t *>(buf.levels + d.def_off);
+
+    pq_page_result out;
+    out.status = PQ_OK;
+    out.stage = PQ_STAGE_NONE;
+    out.detail = 0;
+    out.n_decoded = 0;
+    out.not_null = 0;
+    out.n_levels = 0;
+    out.consumed = 0;
+
+    // ---- read(): where each decoder's bytes are (see data_page_wg) ----
+    const bool konst = d.max_rep == 0;
+    const uint32_t wr = bits_len16(d.max_rep), wdw = bits_len16(d.max_def);
+    Section rep{S, 0, PQ_OK, 0, false}, def{S, 0, PQ_OK, 0, false};
+    int64_t vpos = 0;
+    if (!konst) {
+        if (d.kind == PQ_KIND_PAGE_V1) {
+            rep = section_init_size(S, len, wr);
+            if (rep.init_status != PQ_OK) {
+                out.status = rep.init_status;
+                out.stage = PQ_STAGE_REP_INIT;
+            } else {
+                vpos = rep.consumed_by_init;
+                def = section_init_size(S + vpos, len - vpos, wdw);
+                if (def.init_status != PQ_OK) {
+                    out.status = def.init_status;
+                    out.stage = PQ_STAGE_DEF_INIT;
+                } else {
+                    vpos += def.consumed_by_init;
+                }
+            }
+        } else {
+            const int64_t lv = (int64_t)d.rep_len + (int64_t)d.def_len;
+            if (lv > 0) {
+                if (lv > len) {
+                    out.status = len <= 0 ? PQ_EOF : PQ_UNEXPECTED_EOF;
+                    out.stage = PQ_STAGE_REP_INIT;
+                }
+                rep.S = S;
+                rep.len = d.rep_len;
+                rep.no_reader = d.rep_len == 0;
+                def.S = S + d.rep_len;
+                def.len = d.def_len;
+                def.no_reader = d.def_len == 0;
+                vpos = lv;
+            } else {
+                rep.no_reader = true;
+                def.no_reader = true;
+            }
+        }
+    } else if (d.kind == PQ_KIND_PAGE_V2) {
+        const int64_t lv = (int64_t)d.rep_len + (int64_t)d.def_len;
+        if (lv > len) {
+            out.status = len <= 0 ? PQ_EOF : PQ_UNEXPECTED_EOF;
+            out.stage = PQ_STAGE_REP_INIT;
+        }
+        vpos = lv;
+    }
+    if (out.status != PQ_OK) {
+        if (lane == 0) results[page] = out;
+        return;
+    }
+
+    // ---- ReadValues: levels ----
+    int32_t lvl_status = PQ_OK, lvl_stage = PQ_STAGE_NONE;
+    uint32_t not_null = 0;
+    if (size != 0) {
+        HybridResult rr = konst ? const_levels_wave(rep_dst, size, d.max_rep, lane)
+                                : run_section_wave<HY_LEVELS, uint32_t>(L, rep, wr, size, rep_dst, nullptr, 0,
+                                                                         d.max_rep, lane);
+        if (rr.status != PQ_OK) {
+            lvl_status = rr.status;
+            lvl_stage = PQ_STAGE_REP;
+        } else {
+            HybridResult dr = konst ? const_levels_wave(def_dst, size, d.max_def, lane)
+                                    : run_section_wave<HY_LEVELS, uint32_t>(L, def, wdw, size, def_dst, nullptr, 0,
+                                                                             d.max_def, lane);
+            if (dr.status != PQ_OK) {
+                lvl_status = dr.status;
+                lvl_stage = PQ_STAGE_DEF;
+            } else {
+                not_null = dr.count_max;
+            }
+        }
+    }
+    const uint32_t nvals = (lvl_status == PQ_OK) ? not_null : 0;
+
+    // ---- values ----
+    const uint8_t *VS = S + vpos;
+    const int64_t vlen = len - vpos;
+    int32_t v_init = PQ_OK, v_status = PQ_OK;
+    uint32_t v_count = 0;
+    if (d.value_kind == PQ_KIND_DICT) {
+        WaveDict wd{buf.dict + d.dict_off, ldict};
+        HybridResult vr;
+        if (d.elem_size == 8)
+            vr = dict_values_wave<uint64_t>(L, VS, vlen, nvals, reinterpret_cast<uint64_t *>(buf.values + d.dst_off), wd,
+                                            d.dict_len, &v_init, lane);
+        else
+            vr = dict_values_wave<uint32_t>(L, VS, vlen, nvals, reinterpret_cast<uint32_t *>(buf.values + d.dst_off), wd,
+                                            d.dict_len, &v_init, lane);
+        v_status = vr.status;
+        v_count = vr.n_decoded;
+    } else {
+        WaveDeltaResult vr;
+        if (d.value_kind == PQ_KIND_DELTA64)
+            vr = delta_wave<uint64_t>(L.window, VS, vlen, nvals, reinterpret_cast<uint64_t *>(buf.values + d.dst_off), lane);
+        else
+            vr = delta_wave<uint32_t>(L.window, VS, vlen, nvals, reinterpret_cast<uint32_t *>(buf.values + d.dst_off), lane);
+        if (vr.status == kNeedGeneric) {
+            // a layout other than 128 / 4: the workgroup-per-page sweep redoes the page
+            if (lane == 0) {
+                out.status = kNeedGeneric;
+                results[page] = out;
+                *flag = epoch;
+            }
+            return;
+        }
+        if (vr.init_failed) v_init = vr.status;
+        v_status = vr.status;
+        v_count = vr.n_decoded;
+    }
+    finish_page(out, v_init, v_status, v_count, lvl_status, lvl_stage, not_null, nvals, size);
+    if (lane == 0) results[page] = out;
+}
+
 // Completes the delta pages whose layout the tiled path declined: one lane per page.
 __global__ __launch_bounds__(kWave) void delta_serial_kernel(const pq_page_desc *__restrict__ descs,
                                                              const uint32_t *__restrict__ ids, uint32_t count,
@@ -495,11 +795,22 @@ __global__ __launch_bounds__(kWave) void delta_serial_kernel(const pq_page_desc 
 
 // ---------------------------------------------------------------------------
 
+static size_t wave_lds_bytes(uint32_t dict_lds_bytes)
+{
+    return align16((uint32_t)sizeof(HybridWaveLds) * (kWG / kWave)) + dict_lds_bytes;
+}
+
 hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
                                uint32_t count, PageBuffers buf, pq_page_result *d_results,
-                               uint32_t dict_lds_bytes)
+                               uint32_t dict_lds_bytes, const WaveLaunch &wl)
 {
     if (count == 0) return hipSuccess;
+    if (count >= wl.min_pages) {
+        const uint32_t grid = (count + kWG / kWave - 1) / (kWG / kWave);
+        hipLaunchKernelGGL(stream_wave_kernel, dim3(grid), dim3(kWG), wave_lds_bytes(wl.dict_lds_bytes), s, d_descs,
+                           d_ids, count, buf, d_results, wl.dict_lds_bytes, wl.dict_lds_off);
+        return hipGetLastError();
+    }
     const size_t shmem = align16(sizeof(HybridShared)) + dict_lds_bytes;
     hipLaunchKernelGGL(stream_pages_kernel, dim3(count), dim3(kWG), shmem, s, d_descs, d_ids, buf, d_results,
                        dict_lds_bytes);
@@ -556,12 +867,22 @@ hipError_t launch_delta_serial(hipStream_t s, const pq_page_desc *d_descs, const
 
 hipError_t launch_data_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
                              uint32_t count, PageBuffers buf, pq_page_result *d_results,
-                             uint32_t dict_lds_bytes)
+                             uint32_t dict_lds_bytes, const WaveLaunch &wl, uint32_t *d_flag, uint32_t epoch)
 {
     if (count == 0) return hipSuccess;
     const size_t shmem = align16(sizeof(PageShared)) + dict_lds_bytes;
-    hipLaunchKernelGGL(data_pages_kernel, dim3(count), dim3(kWG), shmem, s, d_descs, d_ids, buf, d_results,
-                       dict_lds_bytes);
+    if (count >= wl.min_pages) {
+        const uint32_t grid = (count + kWG / kWave - 1) / (kWG / kWave);
+        hipLaunchKernelGGL(data_wave_kernel, dim3(grid), dim3(kWG), wave_lds_bytes(wl.dict_lds_bytes), s, d_descs,
+                           d_ids, count, buf, d_results, wl.dict_lds_bytes, wl.dict_lds_off, d_flag, epoch);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(data_pages_kernel<true>, dim3(min(count, 256u)), dim3(kWG), shmem, s, d_descs, d_ids,
+                           count, buf, d_results, dict_lds_bytes, d_flag, epoch);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(data_pages_kernel<false>, dim3(count), dim3(kWG), shmem, s, d_descs, d_ids, count, buf,
+                       d_results, dict_lds_bytes, d_flag, epoch);
     return hipGetLastError();
 }
 

@@ -22,11 +22,20 @@ struct PageBuffers {
     const uint8_t *dict;
 };
 
+// How the one-wave-per-descriptor kernels are used: from min_pages descriptors on; when every
+// dictionary user of the plan reads the same dictionary (dict_lds_bytes long at dict_lds_off
+// in the dictionary buffer, at most kDictLdsMax) each workgroup keeps a copy of it in LDS.
+struct WaveLaunch {
+    uint32_t min_pages;
+    uint32_t dict_lds_bytes;
+    uint64_t dict_lds_off;
+};
+
 // ids: device array of `count` descriptor indices handled by this launch.
 // dict_lds_bytes: LDS set aside for caching a page's dictionary (0 = gather from global).
 hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
                                uint32_t count, PageBuffers buf, pq_page_result *d_results,
-                               uint32_t dict_lds_bytes);
+                               uint32_t dict_lds_bytes, const WaveLaunch &wl);
 // wave_min_pages: from this many pages on, the one-wave-per-page kernel runs first and a
 // sweep kernel (woken through *d_flag == epoch) finishes the pages it declined.
 // *needs_serial: launch_delta_serial must follow for these descriptors.
@@ -36,7 +45,7 @@ hipError_t launch_delta_pages(hipStream_t s, int bits, const pq_page_desc *d_des
                               uint32_t epoch, bool *needs_serial);
 hipError_t launch_data_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
                              uint32_t count, PageBuffers buf, pq_page_result *d_results,
-                             uint32_t dict_lds_bytes);
+                             uint32_t dict_lds_bytes, const WaveLaunch &wl, uint32_t *d_flag, uint32_t epoch);
 
 // Finishes, one lane per page, the delta descriptors among ids[0..count) that the
 // tiled kernels marked as needing the serial path; a no-op for all others.

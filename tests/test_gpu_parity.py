@@ -16,9 +16,13 @@ pytestmark = pytest.mark.gpu
 K = capi
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["wave_per_page", "workgroup_per_page"])
+def ctx(request):
+    """Every test runs under both kernel selections for hybrid / dictionary / level streams and
+    data pages: one wave per descriptor (forced from the first page on) and one workgroup per
+    descriptor.  The delta tests switch their own option as well."""
     c = capi.Context(0)
+    c.set_option(K.OPT_HYBRID_WAVE_MIN_PAGES, 0 if request.param == "wave_per_page" else 1 << 30)
     yield c
     c.close()
 
