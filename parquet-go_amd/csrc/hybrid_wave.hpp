@@ -4,14 +4,14 @@
 // helpers, encoding/hybrid-decoder.go:70-170), organised so that a wave never waits on
 // another one: it owns a stream, a private LDS window that advances by a fixed stride
 // (the next window's loads are issued a whole window ahead) and a 64-entry piece table.
-// Per output tile of up to 256 values the wave
+// Per output tile of up to 512 values the wave
 //   1. walks run headers on the SCALAR unit (1..4-byte ULEB128 headers and the RLE value
 //      are taken from three broadcast LDS words with 32-bit arithmetic; anything unusual
 //      goes through a checked byte-wise parse) and records each run, cut at the tile and
 //      window boundaries, as a piece {first position, RLE flag, value | bit address},
-//   2. maps positions to pieces: a piece marks its first position in a 256-byte LDS
+//   2. maps positions to pieces: a piece marks its first position in a 512-byte LDS
 //      array, a DPP prefix sum over the marks numbers the pieces,
-//   3. expands: every lane produces 4 adjacent values (funnel read of two LDS words for
+//   3. expands: every lane produces 2 x 4 adjacent values (funnel read of two LDS words for
 //      bit-packed pieces), optionally gathers them through a dictionary or counts the
 //      ones equal to the maximum level, and writes 16 or 32 bytes with non-temporal stores.
 #pragma once
@@ -24,12 +24,14 @@ namespace pq {
 constexpr int kHwChunk = kDwChunk;              // bytes of the stream in the LDS window
 constexpr int kHwGuard = 64;                    // >= header (10) + RLE value (4) and >= one group (32)
 constexpr int kHwStride = kHwChunk - kHwGuard;  // distance between consecutive windows
-constexpr int kHwTile = 256;                    // values per tile (4 per lane)
+constexpr int kHwQuads = 2;                     // 4-value quads per lane and tile
+constexpr int kHwTile = 256 * kHwQuads;         // values per tile
 constexpr int kHwSlack = 12;                    // zeroed words behind the window (a last group may hang over)
+constexpr uint32_t kHwMaxBit = (uint32_t)(kHwChunk + 4 * kHwSlack - 8) * 8u;  // highest bit address a funnel read may use
 
 struct HybridWaveLds {
     uint32_t window[kHwChunk / 4 + kHwSlack];
-    uint32_t marks[kWave];  // one byte per tile position: 1 = a piece starts here
+    uint32_t marks[kHwTile / 4];  // one byte per tile position: 1 = a piece starts here
     uint2 pieces[kWave];    // x = first position | RLE flag << 31, y = value | bit address
 };
 
@@ -227,6 +229,129 @@ __device__ __forceinline__ void hw_store4(OutT *p, const OutT *out, uint32_t val
         if (valid & (1u << k)) p[k] = out[k];
 }
 
+// What a tile's expansion needs besides the tile itself.
+template <typename OutT>
+struct HwSink {
+    OutT *dst;
+    const OutT *dict;
+    uint32_t dict_len;   // > 0 (callers hand an empty dictionary over as "every key is bad")
+    uint32_t max_level;
+    uint32_t w;
+    bool vec_ok;
+    bool no_dict;        // DICT with an empty dictionary: every key is out of range
+};
+
+// Expand one tile: positions [0, clip) go to dst[v ... v + clip).  np pieces; solo: the single
+// piece {sk, pl} never went through LDS.  Lane l owns the quads that start at tile positions
+// 256 q + 4 l - phase, which are 4-element aligned in memory.
+template <int MODE, typename OutT>
+__device__ __forceinline__ void hw_expand(HybridWaveLds &L, const HwSink<OutT> &sink, uint32_t np, bool solo,
+                                          uint32_t sk0, uint32_t pl0, uint32_t clip, uint32_t phase, uint32_t v,
+                                          int lane, uint32_t &local_count, bool &bad_index)
+{
+    const uint32_t w = sink.w;
+    if (!solo) wave_sync();
+    const uint32_t jbase = 4u * (uint32_t)lane - phase;  // tile position of this lane's first value
+    uint32_t key[kHwQuads][4];
+    if (np == 1) {
+        uint32_t skv = sk0, plv = pl0;
+        if (!solo) {
+            skv = L.pieces[0].x;
+            plv = L.pieces[0].y;
+        }
+        const uint32_t sk = uni(skv), pl = uni(plv);
+        if (sk & 0x80000000u) {
+#pragma unroll
+            for (int q = 0; q < kHwQuads; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) key[q][k] = pl;
+        } else {
+            // positions outside [0, clip) may point anywhere: their bit address is clamped into
+            // the window and their value is never stored
+            uint32_t bit0 = pl + (uint32_t)__mul24((int)jbase, (int)w);
+            asm volatile("" : "+v"(bit0));  // keep the per-position offsets below on the scalar unit
+#pragma unroll
+            for (int q = 0; q < kHwQuads; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    key[q][k] = extract32(L.window, min(bit0 + (uint32_t)(256 * q + k) * w, kHwMaxBit), w);
+        }
+    } else {
+        uint32_t x[kHwQuads], packed = 0;
+#pragma unroll
+        for (int q = 0; q < kHwQuads; ++q) {
+            uint32_t m = L.marks[kWave * q + lane];
+            m += m << 8;
+            m += m << 16;  // byte k = pieces started at or before position k of this quad
+            x[q] = m;
+            packed |= (m >> 24) << (16 * q);
+        }
+        const uint32_t incl = wave_scan_u32(packed);
+        uint32_t before = 0;  // pieces started in the quads of lower q
+#pragma unroll
+        for (int q = 0; q < kHwQuads; ++q) {
+            const uint32_t excl = before + ((incl >> (16 * q)) & 0xffffu) - (x[q] >> 24);
+            before += (wave_last_u32(incl) >> (16 * q)) & 0xffffu;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t j = jbase + (uint32_t)(256 * q + k);
+                const uint32_t id = (excl + ((x[q] >> (8 * k)) & 0xffu) - 1u) & (uint32_t)(kWave - 1);
+                const uint2 rec = L.pieces[id];
+                const uint32_t rle = (uint32_t)((int32_t)rec.x >> 31);  // all ones for an RLE piece
+                const uint32_t bit = min(rec.y + __umul24((j - rec.x) & 0x3ffu, w), kHwMaxBit) & ~rle;
+                key[q][k] = (extract32(L.window, bit, w) & ~rle) | (rec.y & rle);
+            }
+        }
+    }
+    // a quad is whole, empty or (at the edges of the tile) partly inside [0, clip)
+    bool whole[kHwQuads];
+    bool ragged = !sink.vec_ok;
+#pragma unroll
+    for (int q = 0; q < kHwQuads; ++q) {
+        const int32_t j0 = (int32_t)jbase + 256 * q;  // >= -3
+        whole[q] = j0 >= 0 && j0 + 3 < (int32_t)clip;
+        ragged |= j0 < (int32_t)clip && !whole[q];
+    }
+    const bool edge = __builtin_amdgcn_ballot_w64(ragged) != 0ull;
+#pragma unroll
+    for (int q = 0; q < kHwQuads; ++q) {
+        OutT out[4];
+        bool inside[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (MODE == HY_DICT) {
+                inside[k] = key[q][k] < sink.dict_len && !sink.no_dict;
+                out[k] = sink.dict[inside[k] ? key[q][k] : 0u];
+            } else {
+                inside[k] = true;
+                out[k] = (OutT)key[q][k];
+            }
+        }
+        // the quad starts at dst + v - phase + 256 q + 4 lane
+        OutT *qp = sink.dst + ((int64_t)v - (int64_t)phase + 256 * q + 4 * (int64_t)lane);
+        if (!edge) {
+            if (whole[q]) {
+                if (MODE == HY_DICT) bad_index |= !(inside[0] && inside[1] && inside[2] && inside[3]);
+                if (MODE == HY_LEVELS) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) local_count += key[q][k] == sink.max_level ? 1u : 0u;
+                }
+                hw_store4<OutT>(qp, out, 0xfu, true);
+            }
+        } else {
+            uint32_t valid = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool ok = jbase + (uint32_t)(256 * q + k) < clip;  // also false "below zero"
+                valid |= ok ? 1u << k : 0u;
+                if (MODE == HY_DICT) bad_index |= ok && !inside[k];
+                if (MODE == HY_LEVELS) local_count += (ok && key[q][k] == sink.max_level) ? 1u : 0u;
+            }
+            hw_store4<OutT>(qp, out, valid, sink.vec_ok);
+        }
+    }
+}
+
 // Decode n values of the stream [S, S + len) at bit width w into dst with ONE wave.
 // Modes as in hybrid_stream.  `dict` may point to LDS or global memory.
 template <int MODE, typename OutT>
@@ -258,7 +383,8 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
     int64_t c0 = chunk_base(S, 0);
     wave_fetch(pf, S, c0, len, lane);
     if (lane < kHwSlack) L.window[kHwChunk / 4 + lane] = 0;
-    L.marks[lane] = 0;
+#pragma unroll
+    for (int q = 0; q < kHwQuads; ++q) L.marks[kWave * q + lane] = 0;
     wave_commit_clean(L.window, pf, c0, len, lane);
     wave_sync();
 
@@ -276,6 +402,15 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
     hc.vbmask = 0xffffffffu >> (32u - 8u * hc.vb);
     hc.wmask = w >= 32u ? 0xffffffffu : (1u << w) - 1u;
 
+    HwSink<OutT> sink;
+    sink.dst = dst;
+    sink.no_dict = MODE == HY_DICT && dict_len == 0u;
+    sink.dict = sink.no_dict ? reinterpret_cast<const OutT *>(L.window) : dict;  // something loadable
+    sink.dict_len = dict_len;
+    sink.max_level = max_level;
+    sink.w = w;
+    sink.vec_ok = vec_ok;
+
     uint32_t local_count = 0;  // LEVELS: values equal to max_level seen by this lane
     bool bad_index = false;    // DICT: a key outside the dictionary seen by this lane
 
@@ -286,46 +421,89 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
         const int64_t left = len - c0;
         const uint32_t lim = left > (int64_t)(1 << 30) ? (1u << 30) : (left < 0 ? 0u : (uint32_t)left);
         const uint32_t wl = min(lim, (uint32_t)kHwChunk);  // valid stream bytes in the window
+        // a run header or a group may start at offsets below this one
+        const uint32_t o_end = tail ? 0xffffffffu : (uint32_t)(kHwChunk - kHwGuard) + 1u;
         bool done = false;
 
-        // ---- tiles decodable from this window ----
         while (true) {
+        // ---- long bit-packed runs: whole tiles straight from the window, nothing through LDS ----
+        while (st.v < n && st.o < o_end) {
+            uint32_t groups = st.pcount, o = st.o;
+            if (st.pend == 0) {
+                if (o >= wl) break;
+                const uint32_t b0 = (uni(L.window[o >> 2]) >> ((o & 3u) * 8u)) & 0xffu;
+                if (b0 >= 0x80u || (b0 & 1u) == 0u || b0 < 17u) break;  // not a one-byte header of >= 8 groups
+                groups = b0 >> 1;
+                o += 1u;
+            } else if (st.pend != 2) {
+                break;
+            }
             const uint32_t phase = (st.v + mis) & 3u;
             const uint32_t cap = (uint32_t)kHwTile - phase;
+            const uint32_t g = min(groups, min(cap >> 3, (n - st.v + 7u) >> 3));
+            // the generic path below packs short leftovers with what follows and handles the
+            // ends of the window and of the stream
+            if (16u * g < cap || o + g * w > wl) break;
+            const uint32_t clip = min(8u * g, n - st.v);
+            hw_expand<MODE, OutT>(L, sink, 1, true, 0, o * 8u, clip, phase, st.v, lane, local_count, bad_index);
+            st.v += clip;
+            st.o = o + g * w;
+            st.pcount = groups - g;
+            st.pend = st.pcount != 0u ? 2u : 0u;
+        }
+        if (st.v >= n) { done = true; break; }
+
+        // ---- one tile of anything else ----
+        {
+            const uint32_t phase = (st.v + mis) & 3u;
+            const uint32_t cap = (uint32_t)kHwTile - phase;
+            const uint32_t want = min(cap, n - st.v);  // values this tile may hold
             uint32_t fill = 0, np = 0;
+            uint32_t sk0 = 0, pl0 = 0;
+            bool solo = false;         // the tile is one piece that never went through LDS
             bool want_window = false;
-            while (fill < cap && np < (uint32_t)kWave && st.v + fill < n) {
-                const bool in_window = tail || st.o + (uint32_t)kHwGuard <= (uint32_t)kHwChunk;
+            while (fill < want && np < (uint32_t)kWave) {
+                if (st.o >= o_end) { want_window = true; break; }
                 if (st.pend == 0) {
-                    if (!in_window) { want_window = true; break; }
                     // peek at the header byte: short runs with one-byte headers go through the
                     // span parse, 64 candidate positions at a time
                     const uint32_t b0 = (uni(L.window[st.o >> 2]) >> ((st.o & 3u) * 8u)) & 0xffu;
-                    const bool long_bp = (b0 & 0x81u) == 1u && b0 >= 17u;  // 8 groups and more
-                    const uint32_t room = min(cap - fill, n - st.v - fill);
-                    if (b0 < 0x80u && !long_bp && st.o < wl) {
-                        uint32_t got = 0, o_next = 0;
-                        const uint32_t taken = hw_span(L, st.o, wl, hc, room, np, fill, phase, lane, &got, &o_next);
-                        if (taken != 0u) {
-                            np += taken;
-                            fill += got;
-                            st.o = o_next;
-                            continue;
+                    const uint32_t room = want - fill;
+                    if (b0 < 0x80u && st.o < wl) {
+                        if ((b0 & 1u) != 0u && b0 >= 17u) {
+                            // a bit-packed run of 8 groups and more: no span parse
+                            if (8u * (b0 >> 1) > room && 2u * fill >= cap) break;
+                            st.pend = 2;
+                            st.pcount = b0 >> 1;
+                            st.o += 1u;
+                        } else {
+                            uint32_t got = 0, o_next = 0;
+                            const uint32_t taken = hw_span(L, st.o, wl, hc, room, np, fill, phase, lane, &got, &o_next);
+                            if (taken != 0u) {
+                                np += taken;
+                                fill += got;
+                                st.o = o_next;
+                                continue;
+                            }
+                            // the first run is malformed, cut short or does not fit: in a tile that
+                            // is already half full leave it to the next one, else take it apart below
+                            if (2u * fill >= cap) break;
                         }
-                        // the first run is malformed, cut short or does not fit: in a tile that is
-                        // already half full leave it to the next one, else take it apart below
-                        if (2u * fill >= cap) break;
-                    } else if (long_bp && 8u * (b0 >> 1) > room && 2u * fill >= cap) {
-                        break;
                     }
-                    if (!hw_header_fast(st, L.window, lim, w)) {
+                    if (st.pend == 0 && !hw_header_fast(st, L.window, lim, w)) {
                         hw_header_slow(st, B, lim, w);
                         if (st.status != PQ_OK) break;
                     }
                 }
                 if (st.pend == 1) {
-                    const uint32_t take = min(st.pcount, min(cap - fill, n - st.v - fill));
-                    put_piece(L, np, fill | 0x80000000u, st.pvalue, fill + phase, lane);
+                    const uint32_t take = min(st.pcount, want - fill);
+                    if (np == 0 && take == want) {
+                        solo = true;
+                        sk0 = 0x80000000u;
+                        pl0 = st.pvalue;
+                    } else {
+                        put_piece(L, np, fill | 0x80000000u, st.pvalue, fill + phase, lane);
+                    }
                     ++np;
                     fill += take;
                     st.pcount -= take;
@@ -333,78 +511,47 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
                 } else {
                     // readBitPackedRun (hybrid-decoder.go:138-149): a group is readable while at
                     // least one byte is left; pieces are whole groups that lie inside the window
-                    if (!in_window) { want_window = true; break; }
-                    uint32_t g = min(st.pcount, min((cap - fill) >> 3, (n - st.v - fill + 7u) >> 3));
+                    uint32_t g = min(st.pcount, min((cap - fill) >> 3, (want - fill + 7u) >> 3));
                     if (g == 0) break;  // fewer than 8 positions left in the tile
-                    if (st.o + g * w > min(lim, (uint32_t)kHwChunk)) {
+                    if (st.o + g * w > wl) {
                         if (st.o >= lim) { st.status = PQ_EOF; break; }
-                        const uint32_t feed = (lim - st.o + w - 1u) / w;          // groups the stream can feed
+                        const uint32_t feed = (lim - st.o + w - 1u) / w;  // groups the stream can feed
                         const uint32_t fit = tail ? feed : ((uint32_t)kHwChunk - st.o) / w;
                         g = min(g, min(feed, fit));
                         if (g == 0) { want_window = true; break; }
                     }
-                    put_piece(L, np, fill, st.o * 8u, fill + phase, lane);
+                    // a tile left with fewer than 16 free positions is closed
+                    const bool closes = fill + 8u * g + 16u > want;
+                    if (np == 0 && closes) {
+                        solo = true;
+                        sk0 = 0;
+                        pl0 = st.o * 8u;
+                    } else {
+                        put_piece(L, np, fill, st.o * 8u, fill + phase, lane);
+                    }
                     ++np;
                     fill += 8u * g;
                     st.o += g * w;
                     st.pcount -= g;
                     if (st.pcount == 0) st.pend = 0;
+                    if (closes) break;
                 }
             }
 
             // ---- expand the tile ----
-            const uint32_t clip = min(fill, n - st.v);  // a last group may carry values beyond n
-            if (clip != 0) {
-                uint32_t x = 0, excl = 0;
-                wave_sync();
-                const uint2 rec0 = L.pieces[0];
-                if (np > 1) {
-                    x = L.marks[lane];
-                    x += x << 8;
-                    x += x << 16;  // byte k = pieces started at or before position k of this quad
-                    const uint32_t tot = x >> 24;
-                    excl = wave_scan_u32(tot) - tot;
-                }
-                OutT out[4];
-                uint32_t valid = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t j = 4u * (uint32_t)lane + (uint32_t)k - phase;  // position in the tile
-                    const bool ok = j < clip;                                        // also false for j "negative"
-                    uint32_t sk = rec0.x, pl = rec0.y;
-                    if (np > 1) {
-                        const uint32_t id = (excl + ((x >> (8 * k)) & 0xffu) - 1u) & (uint32_t)(kWave - 1);
-                        const uint2 rec = L.pieces[id];
-                        sk = rec.x;
-                        pl = rec.y;
-                    }
-                    const bool rle = (sk & 0x80000000u) != 0u;
-                    const uint32_t rel = ok ? j - (sk & 0xffffu) : 0u;
-                    const uint32_t bit = rle ? 0u : pl + rel * w;
-                    uint32_t key = extract32(L.window, ok ? bit : 0u, w);
-                    if (rle) key = pl;
-                    out[k] = 0;
-                    if (ok) {
-                        valid |= 1u << k;
-                        if (MODE == HY_DICT) {
-                            if (key < dict_len) out[k] = dict[key]; else bad_index = true;
-                        } else {
-                            out[k] = (OutT)key;
-                            if (MODE == HY_LEVELS && key == max_level) ++local_count;
-                        }
-                    }
-                }
-                // the quad of lane l starts at dst + v - phase + 4l, 4 elements aligned
-                hw_store4<OutT>(dst + ((int64_t)st.v - (int64_t)phase + 4 * (int64_t)lane), out, valid, vec_ok);
-            }
-            if (np != 0) {
+            const uint32_t clip = min(fill, want);  // a last group may carry values beyond n
+            if (clip != 0)
+                hw_expand<MODE, OutT>(L, sink, np, solo, sk0, pl0, clip, phase, st.v, lane, local_count, bad_index);
+            if (np != 0 && !solo) {
                 wave_sync();  // the marks were read; the next walk sets its own
-                L.marks[lane] = 0;
+#pragma unroll
+                for (int q = 0; q < kHwQuads; ++q) L.marks[kWave * q + lane] = 0;
                 wave_sync();
             }
             st.v += clip;
             if (st.status != PQ_OK || st.v >= n) { done = true; break; }
             if (want_window) break;
+        }
         }
         if (done) break;
         wave_sync();
