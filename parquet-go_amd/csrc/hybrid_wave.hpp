@@ -32,7 +32,8 @@ constexpr uint32_t kHwMaxBit = (uint32_t)(kHwChunk + 4 * kHwSlack - 8) * 8u;  //
 struct HybridWaveLds {
     uint32_t window[kHwChunk / 4 + kHwSlack];
     uint32_t marks[kHwTile / 4];  // one byte per tile position: 1 = a piece starts here
-    uint2 pieces[kWave];    // x = first position | RLE flag << 31, y = value | bit address
+    uint2 pieces[kWave];    // RLE piece: x = ~0, y = the value; bit-packed: x = 0, y = bit address of
+                            // (virtual) tile position 0, so that position j sits at y + j * w
 };
 
 // wave_commit that also zeroes what lies past the end of the stream inside the last
@@ -179,7 +180,7 @@ __device__ __forceinline__ uint32_t hw_span(HybridWaveLds &L, uint32_t o, uint32
     const uint32_t b0 = lo & 0xffu;
     const uint32_t cnt = b0 >> 1;
     const bool isbp = (b0 & 1u) != 0u;
-    const uint32_t nbytes = isbp ? 1u + cnt * hc.w : 1u + hc.vb;
+    const uint32_t nbytes = isbp ? 1u + __umul24(cnt, hc.w) : 1u + hc.vb;
     const uint32_t nvals = isbp ? cnt * 8u : cnt;
     const bool ok = b0 < 0x80u && cnt != 0u && p + nbytes <= wl && (isbp || (val & ~hc.wmask) == 0u);
     const uint32_t nextlane = (uint32_t)lane + nbytes;
@@ -206,7 +207,7 @@ __device__ __forceinline__ uint32_t hw_span(HybridWaveLds &L, uint32_t o, uint32
     *o_next = o + (untaken != 0ull ? (uint32_t)__builtin_ctzll(untaken) : cur);
     if (take) {
         const uint32_t start = fill + incl - nvals;
-        L.pieces[np + rank] = make_uint2(isbp ? start : (start | 0x80000000u), isbp ? (p + 1u) * 8u : val);
+        L.pieces[np + rank] = make_uint2(isbp ? 0u : 0xffffffffu, isbp ? (p + 1u) * 8u - __umul24(start, hc.w) : val);
         reinterpret_cast<uint8_t *>(L.marks)[phase + start] = 1;
     }
     return (uint32_t)__builtin_popcountll(tmask);
@@ -260,7 +261,7 @@ __device__ __forceinline__ void hw_expand(HybridWaveLds &L, const HwSink<OutT> &
             plv = L.pieces[0].y;
         }
         const uint32_t sk = uni(skv), pl = uni(plv);
-        if (sk & 0x80000000u) {
+        if (sk != 0u) {
 #pragma unroll
             for (int q = 0; q < kHwQuads; ++q)
 #pragma unroll
@@ -287,6 +288,8 @@ __device__ __forceinline__ void hw_expand(HybridWaveLds &L, const HwSink<OutT> &
             packed |= (m >> 24) << (16 * q);
         }
         const uint32_t incl = wave_scan_u32(packed);
+        uint32_t jw = (uint32_t)__mul24((int)jbase, (int)w);
+        asm volatile("" : "+v"(jw));  // keep the per-position offsets below on the scalar unit
         uint32_t before = 0;  // pieces started in the quads of lower q
 #pragma unroll
         for (int q = 0; q < kHwQuads; ++q) {
@@ -294,12 +297,10 @@ __device__ __forceinline__ void hw_expand(HybridWaveLds &L, const HwSink<OutT> &
             before += (wave_last_u32(incl) >> (16 * q)) & 0xffffu;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t j = jbase + (uint32_t)(256 * q + k);
                 const uint32_t id = (excl + ((x[q] >> (8 * k)) & 0xffu) - 1u) & (uint32_t)(kWave - 1);
                 const uint2 rec = L.pieces[id];
-                const uint32_t rle = (uint32_t)((int32_t)rec.x >> 31);  // all ones for an RLE piece
-                const uint32_t bit = min(rec.y + __umul24((j - rec.x) & 0x3ffu, w), kHwMaxBit) & ~rle;
-                key[q][k] = (extract32(L.window, bit, w) & ~rle) | (rec.y & rle);
+                const uint32_t bit = min(rec.y + jw + (uint32_t)(256 * q + k) * w, kHwMaxBit) & ~rec.x;
+                key[q][k] = (extract32(L.window, bit, w) & ~rec.x) | (rec.y & rec.x);
             }
         }
     }
@@ -312,43 +313,51 @@ __device__ __forceinline__ void hw_expand(HybridWaveLds &L, const HwSink<OutT> &
         whole[q] = j0 >= 0 && j0 + 3 < (int32_t)clip;
         ragged |= j0 < (int32_t)clip && !whole[q];
     }
-    const bool edge = __builtin_amdgcn_ballot_w64(ragged) != 0ull;
+    OutT *const qp0 = sink.dst + ((int64_t)v - (int64_t)phase + 4 * (int64_t)lane);  // quad q: + 256 q
+    const uint32_t dmax = sink.dict_len - 1u;  // no_dict: wraps, every comparison below still holds
+    if (__builtin_amdgcn_ballot_w64(ragged) == 0ull) {
+        // the usual tile: whole quads only, no per-value bookkeeping
 #pragma unroll
-    for (int q = 0; q < kHwQuads; ++q) {
-        OutT out[4];
-        bool inside[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int q = 0; q < kHwQuads; ++q) {
+            OutT out[4];
             if (MODE == HY_DICT) {
-                inside[k] = key[q][k] < sink.dict_len && !sink.no_dict;
-                out[k] = sink.dict[inside[k] ? key[q][k] : 0u];
+                const uint32_t top = max(max(key[q][0], key[q][1]), max(key[q][2], key[q][3]));
+                bad_index |= whole[q] && (top > dmax || sink.no_dict);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) out[k] = sink.dict[sink.no_dict ? 0u : min(key[q][k], dmax)];
             } else {
-                inside[k] = true;
-                out[k] = (OutT)key[q][k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) out[k] = (OutT)key[q][k];
             }
-        }
-        // the quad starts at dst + v - phase + 256 q + 4 lane
-        OutT *qp = sink.dst + ((int64_t)v - (int64_t)phase + 256 * q + 4 * (int64_t)lane);
-        if (!edge) {
             if (whole[q]) {
-                if (MODE == HY_DICT) bad_index |= !(inside[0] && inside[1] && inside[2] && inside[3]);
                 if (MODE == HY_LEVELS) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) local_count += key[q][k] == sink.max_level ? 1u : 0u;
                 }
-                hw_store4<OutT>(qp, out, 0xfu, true);
+                hw_store4<OutT>(qp0 + 256 * q, out, 0xfu, true);
             }
-        } else {
-            uint32_t valid = 0;
+        }
+        return;
+    }
+    // a tile with ragged edges (first or last of a stream, or after a short tile)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool ok = jbase + (uint32_t)(256 * q + k) < clip;  // also false "below zero"
-                valid |= ok ? 1u << k : 0u;
-                if (MODE == HY_DICT) bad_index |= ok && !inside[k];
+    for (int q = 0; q < kHwQuads; ++q) {
+        OutT out[4];
+        uint32_t valid = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = jbase + (uint32_t)(256 * q + k) < clip;  // also false "below zero"
+            valid |= ok ? 1u << k : 0u;
+            if (MODE == HY_DICT) {
+                const bool inside = key[q][k] <= dmax && !sink.no_dict;
+                bad_index |= ok && !inside;
+                out[k] = sink.dict[inside ? key[q][k] : 0u];
+            } else {
+                out[k] = (OutT)key[q][k];
                 if (MODE == HY_LEVELS) local_count += (ok && key[q][k] == sink.max_level) ? 1u : 0u;
             }
-            hw_store4<OutT>(qp, out, valid, sink.vec_ok);
         }
+        hw_store4<OutT>(qp0 + 256 * q, out, valid, sink.vec_ok);
     }
 }
 
@@ -401,6 +410,7 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
     hc.vb = (w + 7u) >> 3;
     hc.vbmask = 0xffffffffu >> (32u - 8u * hc.vb);
     hc.wmask = w >= 32u ? 0xffffffffu : (1u << w) - 1u;
+    const uint32_t rw = 65536u / w + 1u;  // x * rw >> 16 == x / w (or one more) for x < 4096
 
     HwSink<OutT> sink;
     sink.dst = dst;
@@ -432,7 +442,7 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
             if (st.pend == 0) {
                 if (o >= wl) break;
                 const uint32_t b0 = (uni(L.window[o >> 2]) >> ((o & 3u) * 8u)) & 0xffu;
-                if (b0 >= 0x80u || (b0 & 1u) == 0u || b0 < 17u) break;  // not a one-byte header of >= 8 groups
+                if (b0 >= 0x80u || (b0 & 1u) == 0u || b0 < 65u) break;  // not a one-byte header of >= 32 groups
                 groups = b0 >> 1;
                 o += 1u;
             } else if (st.pend != 2) {
@@ -440,10 +450,19 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
             }
             const uint32_t phase = (st.v + mis) & 3u;
             const uint32_t cap = (uint32_t)kHwTile - phase;
-            const uint32_t g = min(groups, min(cap >> 3, (n - st.v + 7u) >> 3));
-            // the generic path below packs short leftovers with what follows and handles the
-            // ends of the window and of the stream
-            if (16u * g < cap || o + g * w > wl) break;
+            uint32_t g = min(groups, min(cap >> 3, (n - st.v + 7u) >> 3));
+            bool cut = false;
+            if (o + g * w > wl) {
+                // the window ends inside the run: take the groups that are wholly in it (the
+                // end of the stream is left to the checked path below)
+                if (tail) break;
+                uint32_t fit = (((uint32_t)kHwChunk - o) * rw) >> 16;  // floor((chunk - o) / w), or one more
+                if (fit * w > (uint32_t)kHwChunk - o) --fit;
+                g = min(g, fit);
+                cut = true;
+            }
+            // short leftovers are packed with what follows by the generic path below
+            if (cut ? g < 8u : 16u * g < cap) break;
             const uint32_t clip = min(8u * g, n - st.v);
             hw_expand<MODE, OutT>(L, sink, 1, true, 0, o * 8u, clip, phase, st.v, lane, local_count, bad_index);
             st.v += clip;
@@ -470,8 +489,8 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
                     const uint32_t b0 = (uni(L.window[st.o >> 2]) >> ((st.o & 3u) * 8u)) & 0xffu;
                     const uint32_t room = want - fill;
                     if (b0 < 0x80u && st.o < wl) {
-                        if ((b0 & 1u) != 0u && b0 >= 17u) {
-                            // a bit-packed run of 8 groups and more: no span parse
+                        if ((b0 & 1u) != 0u && b0 >= 65u) {
+                            // a bit-packed run of 32 groups and more: no span parse
                             if (8u * (b0 >> 1) > room && 2u * fill >= cap) break;
                             st.pend = 2;
                             st.pcount = b0 >> 1;
@@ -499,10 +518,10 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
                     const uint32_t take = min(st.pcount, want - fill);
                     if (np == 0 && take == want) {
                         solo = true;
-                        sk0 = 0x80000000u;
+                        sk0 = 0xffffffffu;
                         pl0 = st.pvalue;
                     } else {
-                        put_piece(L, np, fill | 0x80000000u, st.pvalue, fill + phase, lane);
+                        put_piece(L, np, 0xffffffffu, st.pvalue, fill + phase, lane);
                     }
                     ++np;
                     fill += take;
@@ -527,7 +546,7 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
                         sk0 = 0;
                         pl0 = st.o * 8u;
                     } else {
-                        put_piece(L, np, fill, st.o * 8u, fill + phase, lane);
+                        put_piece(L, np, 0u, st.o * 8u - fill * w, fill + phase, lane);
                     }
                     ++np;
                     fill += 8u * g;

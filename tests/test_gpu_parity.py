@@ -208,6 +208,51 @@ def test_hybrid_fuzz_random_bytes(ctx):
         _check_hybrid(c, c.w)
 
 
+def _random_run_stream(rng, w, target_bytes):
+    """A well-formed stream built run by run (not through the encoder): RLE runs of 1..700
+    repeats and bit-packed runs of 1..70 groups, i.e. one- and two-byte headers, in random
+    order, long enough to cross several staging windows."""
+    out = bytearray()
+    vb = (w + 7) // 8
+    while len(out) < target_bytes:
+        kind = rng.integers(0, 4)
+        if kind == 0:                                   # short RLE
+            cnt, bp = int(rng.integers(1, 20)), False
+        elif kind == 1:                                 # long RLE (two-byte header from 64 on)
+            cnt, bp = int(rng.integers(20, 700)), False
+        elif kind == 2:                                 # short bit-packed
+            cnt, bp = int(rng.integers(1, 6)), True
+        else:                                           # long bit-packed (two-byte header from 64 on)
+            cnt, bp = int(rng.integers(6, 71)), True
+        out += bytes(synth.uleb128((cnt << 1) | (1 if bp else 0)))
+        if bp:
+            out += rng.integers(0, 256, size=cnt * w, dtype=np.uint8).tobytes()
+        else:
+            v = int(rng.integers(0, 1 << w)) if w < 63 else 0
+            out += v.to_bytes(8, "little")[:vb]
+    return np.frombuffer(bytes(out), dtype=np.uint8).copy()
+
+
+def test_hybrid_structured_runs_stress(ctx):
+    """Run lists of every shape, cut at random bytes and pulled to random counts: windows,
+    tiles, the span parse and the checked header path all meet their boundaries here."""
+    rng = _rng(21)
+    cases = []
+    for i in range(260):
+        w = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 20, 24, 25, 31, 32]))
+        s = _random_run_stream(rng, w, int(rng.integers(10, 16000)))
+        if i % 3 == 0:
+            s = s[: int(rng.integers(1, s.size + 1))].copy()      # cut anywhere
+        total_cap = 60000
+        n = int(rng.integers(1, total_cap))
+        c = Case(K.KIND_HYBRID, s, n, bit_width=w)
+        c.w, c.result_src_len = w, s.size
+        cases.append(c)
+    run_cases(ctx, cases, seed=5)
+    for c in cases:
+        _check_hybrid(c, c.w)
+
+
 # ---------------------------------------------------------------------------
 # a5: dictionary pages
 
