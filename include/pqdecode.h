@@ -71,11 +71,12 @@ void pq_ctx_destroy(pq_ctx *ctx);
 int pq_ctx_synchronize(pq_ctx *ctx);
 /* Tuning knobs (no counterpart in the reference).
  * PQ_OPT_DELTA_WAVE_MIN_PAGES: a batch with at least this many delta descriptors of one
- * element size is decoded one wave per page (best when pages outnumber the chip's
- * wave slots); smaller batches use one workgroup per page.  Default 2048. */
+ * element size is decoded one wave per page; smaller batches use one workgroup per page.
+ * Default 1: on MI355X the wave kernel is faster from a single page on (80 us against
+ * 500 us for one 20 000-value page); the knob remains for experiments and tests. */
 #define PQ_OPT_DELTA_WAVE_MIN_PAGES 1
 /* PQ_OPT_HYBRID_WAVE_MIN_PAGES: the same choice for hybrid / dictionary / level streams and
- * whole data pages.  Default 1024. */
+ * whole data pages.  Default 1 (equal up to about 256 pages, the wave kernels ahead beyond). */
 #define PQ_OPT_HYBRID_WAVE_MIN_PAGES 2
 int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value);
 const char *pq_status_string(int status);

@@ -111,7 +111,7 @@ def test_delta_100m_values_round_trip(ctx):
         assert torch.equal(t_out[: 500 * n].view(500, n), torch.from_numpy(expected[:500]).to(dev))
         plan2.close()
     finally:
-        ctx.set_option(capi.OPT_DELTA_WAVE_MIN_PAGES, 2048)
+        ctx.set_option(capi.OPT_DELTA_WAVE_MIN_PAGES, 1)
     # a few pages against the oracle too
     for p in (0, pages // 2, pages - 1):
         r = O.delta_decode64(src[offs[p]: offs[p] + lens[p]], n)

@@ -356,7 +356,7 @@ def _run_delta_both_ways(ctx, cases, bits, seed):
             for c in cases:
                 _check_delta(c, bits)
     finally:
-        ctx.set_option(K.OPT_DELTA_WAVE_MIN_PAGES, 2048)
+        ctx.set_option(K.OPT_DELTA_WAVE_MIN_PAGES, 1)
 
 
 def test_delta_golden_vectors(ctx, golden_dir):
