@@ -242,6 +242,50 @@ struct HwSink {
     bool no_dict;        // DICT with an empty dictionary: every key is out of range
 };
 
+// The tile of the bulk path in its usual shape: bit-packed values only, clip a multiple of 4
+// values, dst + v aligned to 4 elements, so every quad is whole or empty and nothing is tracked
+// per value.  Positions below `split` (a multiple of 8) belong to a piece whose position 0 sits
+// at bit address pl_a, the others to a second piece with (virtual) position 0 at pl_b: the tail
+// of one run and the head of the next share a tile.
+template <int MODE, typename OutT>
+__device__ __forceinline__ void hw_expand_bulk(HybridWaveLds &L, const HwSink<OutT> &sink, uint32_t pl_a,
+                                               uint32_t split, uint32_t pl_b, uint32_t clip, uint32_t v, int lane,
+                                               uint32_t &local_count, bool &bad_index)
+{
+    const uint32_t w = sink.w;
+    const uint32_t jw = __umul24(4u * (uint32_t)lane, w);
+    OutT *const qp0 = sink.dst + ((size_t)v + 4u * (uint32_t)lane);
+    const uint32_t dmax = sink.dict_len - 1u;
+#pragma unroll
+    for (int q = 0; q < kHwQuads; ++q) {
+        uint32_t key[4];
+        // lanes past the end of the tile read a clamped address and store nothing
+        uint32_t bit0 = jw + (4u * (uint32_t)lane + (uint32_t)(256 * q) < split ? pl_a : pl_b);
+        asm volatile("" : "+v"(bit0));  // keep the per-position offsets below on the scalar unit
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            key[k] = extract32(L.window, min(bit0 + (uint32_t)(256 * q + k) * w, kHwMaxBit), w);
+        const bool whole = 4u * (uint32_t)lane + (uint32_t)(256 * q) < clip;
+        OutT out[4];
+        if (MODE == HY_DICT) {
+            const uint32_t top = max(max(key[0], key[1]), max(key[2], key[3]));
+            bad_index |= whole && (top > dmax || sink.no_dict);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[k] = sink.dict[sink.no_dict ? 0u : min(key[k], dmax)];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[k] = (OutT)key[k];
+        }
+        if (whole) {
+            if (MODE == HY_LEVELS) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) local_count += key[k] == sink.max_level ? 1u : 0u;
+            }
+            hw_store4<OutT>(qp0 + 256 * q, out, 0xfu, true);
+        }
+    }
+}
+
 // Expand one tile: positions [0, clip) go to dst[v ... v + clip).  np pieces; solo: the single
 // piece {sk, pl} never went through LDS.  Lane l owns the quads that start at tile positions
 // 256 q + 4 l - phase, which are 4-element aligned in memory.
@@ -450,7 +494,8 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
             }
             const uint32_t phase = (st.v + mis) & 3u;
             const uint32_t cap = (uint32_t)kHwTile - phase;
-            uint32_t g = min(groups, min(cap >> 3, (n - st.v + 7u) >> 3));
+            const uint32_t room = min(cap >> 3, (n - st.v + 7u) >> 3);  // groups the tile may hold
+            uint32_t g = min(groups, room);
             bool cut = false;
             if (o + g * w > wl) {
                 // the window ends inside the run: take the groups that are wholly in it (the
@@ -461,13 +506,44 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
                 g = min(g, fit);
                 cut = true;
             }
-            // short leftovers are packed with what follows by the generic path below
-            if (cut ? g < 8u : 16u * g < cap) break;
-            const uint32_t clip = min(8u * g, n - st.v);
-            hw_expand<MODE, OutT>(L, sink, 1, true, 0, o * 8u, clip, phase, st.v, lane, local_count, bad_index);
+            // the run ends inside the tile: the head of the next long run fills the rest
+            uint32_t g2 = 0, groups2 = 0, o2 = o + g * w;
+            if (!cut && g < room && phase == 0u && vec_ok && o2 < wl && o2 < o_end) {
+                const uint32_t b0 = (uni(L.window[o2 >> 2]) >> ((o2 & 3u) * 8u)) & 0xffu;
+                if (b0 < 0x80u && (b0 & 1u) != 0u && b0 >= 65u) {
+                    groups2 = b0 >> 1;
+                    o2 += 1u;
+                    g2 = min(groups2, room - g);
+                    if (o2 + g2 * w > wl) {
+                        uint32_t fit = 0;
+                        if (!tail && o2 < (uint32_t)kHwChunk) {
+                            fit = (((uint32_t)kHwChunk - o2) * rw) >> 16;
+                            if (fit * w > (uint32_t)kHwChunk - o2) --fit;
+                        }
+                        g2 = min(g2, fit);
+                    }
+                    // the two-piece tile needs whole quads: not where the stream's last values
+                    // end in the middle of one
+                    if (8u * (g + g2) > n - st.v && ((n - st.v) & 3u) != 0u) g2 = 0;
+                }
+            }
+            // short leftovers of a run with nothing to join are packed with what follows by the
+            // generic path below; the few groups in front of a window end go out right here
+            if (g2 == 0u && (cut ? g == 0u : 16u * g < cap)) break;
+            const uint32_t clip = min(8u * (g + g2), n - st.v);
+            if (phase == 0u && (clip & 3u) == 0u && vec_ok)
+                hw_expand_bulk<MODE, OutT>(L, sink, o * 8u, 8u * g, o2 * 8u - 8u * g * w, clip, st.v, lane, local_count,
+                                           bad_index);
+            else  // g2 == 0 here
+                hw_expand<MODE, OutT>(L, sink, 1, true, 0, o * 8u, clip, phase, st.v, lane, local_count, bad_index);
             st.v += clip;
-            st.o = o + g * w;
-            st.pcount = groups - g;
+            if (g2 != 0u) {
+                st.o = o2 + g2 * w;
+                st.pcount = groups2 - g2;
+            } else {
+                st.o = o + g * w;
+                st.pcount = groups - g;
+            }
             st.pend = st.pcount != 0u ? 2u : 0u;
         }
         if (st.v >= n) { done = true; break; }
