@@ -165,11 +165,20 @@ struct HwConst {
 // complete, well-formed runs with a one-byte header that lie wholly inside [0, wl) qualify;
 // the chain stops at the first one that does not.  Of the chain, the leading runs that fit
 // `room` values (and the piece table) are appended to the tile under construction: each of
-// their lanes writes its own piece record and start mark.  Returns the number of runs taken;
-// *taken_values and *o_next (offset of the first header not taken) are set when it is not 0.
+// their lanes writes its own piece record and start mark.  Returns the number of runs taken.
+// nx describes what follows them: the offset of the next header and, when that header belongs
+// to the chain (a well-formed run that merely did not fit), its parsed fields, so that the
+// caller can cut it without parsing it again.
+struct HwNext {
+    uint32_t o;       // window offset of the first header not taken
+    uint32_t values;  // values of the runs taken
+    uint32_t kind;    // 0: unknown (parse it); 1: RLE; 2: bit-packed
+    uint32_t count;   // repeats | groups
+    uint32_t value;   // RLE value
+};
+
 __device__ __forceinline__ uint32_t hw_span(HybridWaveLds &L, uint32_t o, uint32_t wl, const HwConst &hc, uint32_t room,
-                                            uint32_t np, uint32_t fill, uint32_t phase, int lane,
-                                            uint32_t *taken_values, uint32_t *o_next)
+                                            uint32_t np, uint32_t fill, uint32_t phase, int lane, HwNext &nx)
 {
     const uint32_t p = o + (uint32_t)lane;
     const uint32_t i = p >> 2, sh = (p & 3u) * 8u;
@@ -185,6 +194,11 @@ __device__ __forceinline__ uint32_t hw_span(HybridWaveLds &L, uint32_t o, uint32
     const bool ok = b0 < 0x80u && cnt != 0u && p + nbytes <= wl && (isbp || (val & ~hc.wmask) == 0u);
     const uint32_t nextlane = (uint32_t)lane + nbytes;
     const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
+    nx.o = o;
+    nx.values = 0;
+    nx.kind = 0;
+    nx.count = 0;
+    nx.value = 0;
 
     uint32_t cur = 0;
     uint64_t chain = 0;
@@ -200,11 +214,21 @@ __device__ __forceinline__ uint32_t hw_span(HybridWaveLds &L, uint32_t o, uint32
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chain >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chain, 0u));
     const bool take = on && incl <= room && np + rank < (uint32_t)kWave;
     const uint64_t tmask = __builtin_amdgcn_ballot_w64(take);
-    if (tmask == 0ull) return 0;
-    const uint32_t last = 63u - (uint32_t)__builtin_clzll(tmask);
-    *taken_values = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)last);
+    if (tmask != 0ull) {
+        const uint32_t last = 63u - (uint32_t)__builtin_clzll(tmask);
+        nx.values = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)last);
+    }
     const uint64_t untaken = chain & ~tmask;
-    *o_next = o + (untaken != 0ull ? (uint32_t)__builtin_ctzll(untaken) : cur);
+    if (untaken != 0ull) {
+        const uint32_t u = (uint32_t)__builtin_ctzll(untaken);
+        const uint32_t bu = (uint32_t)__builtin_amdgcn_readlane((int)b0, (int)u);
+        nx.o = o + u;
+        nx.kind = (bu & 1u) != 0u ? 2u : 1u;
+        nx.count = bu >> 1;
+        nx.value = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)u);
+    } else {
+        nx.o = o + cur;
+    }
     if (take) {
         const uint32_t start = fill + incl - nvals;
         L.pieces[np + rank] = make_uint2(isbp ? 0u : 0xffffffffu, isbp ? (p + 1u) * 8u - __umul24(start, hc.w) : val);
@@ -572,17 +596,22 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
                             st.pcount = b0 >> 1;
                             st.o += 1u;
                         } else {
-                            uint32_t got = 0, o_next = 0;
-                            const uint32_t taken = hw_span(L, st.o, wl, hc, room, np, fill, phase, lane, &got, &o_next);
-                            if (taken != 0u) {
-                                np += taken;
-                                fill += got;
-                                st.o = o_next;
+                            HwNext nx;
+                            const uint32_t taken = hw_span(L, st.o, wl, hc, room, np, fill, phase, lane, nx);
+                            np += taken;
+                            fill += nx.values;
+                            st.o = nx.o;
+                            if (nx.kind != 0u && np < (uint32_t)kWave && fill < want) {
+                                // a well-formed run that does not fit whole: its head fills the tile,
+                                // the rest stays pending (the piece code below cuts it)
+                                st.pend = nx.kind;
+                                st.pcount = nx.count;
+                                st.pvalue = nx.value;
+                                st.o = nx.o + 1u + (nx.kind == 1u ? hc.vb : 0u);
+                            } else if (taken != 0u) {
                                 continue;
                             }
-                            // the first run is malformed, cut short or does not fit: in a tile that
-                            // is already half full leave it to the next one, else take it apart below
-                            if (2u * fill >= cap) break;
+                            // else: the first run is malformed, cut short or unusual: parsed below
                         }
                     }
                     if (st.pend == 0 && !hw_header_fast(st, L.window, lim, w)) {
