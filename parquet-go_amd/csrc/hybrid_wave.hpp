@@ -200,13 +200,25 @@ __device__ __forceinline__ uint32_t hw_span(HybridWaveLds &L, uint32_t o, uint32
     nx.count = 0;
     nx.value = 0;
 
-    uint32_t cur = 0;
-    uint64_t chain = 0;
-    do {
-        if (((okmask >> cur) & 1ull) == 0ull) break;
-        chain |= 1ull << cur;
-        cur = (uint32_t)__builtin_amdgcn_readlane((int)nextlane, (int)cur);
-    } while (cur < (uint32_t)kWave);
+    // follow the chain from lane 0: chain = lanes that hold real headers, cur = where it leaves
+    // the span (>= 64) or stops at a header that is not simple.  Hand-scheduled: five scalar
+    // instructions between the v_readlane that writes `cur` and the one that uses it as its lane
+    // select cover the four wait states that dependency needs.
+    uint32_t cur;
+    uint64_t chain;
+    asm volatile("s_mov_b64 %[chain], 0\n\t"
+                 "s_mov_b32 %[cur], 0\n"
+                 "1:\n\t"
+                 "s_bitcmp1_b64 %[ok], %[cur]\n\t"
+                 "s_cbranch_scc0 2f\n\t"
+                 "s_bitset1_b64 %[chain], %[cur]\n\t"
+                 "v_readlane_b32 %[cur], %[next], %[cur]\n\t"
+                 "s_cmp_lt_u32 %[cur], 64\n\t"
+                 "s_cbranch_scc1 1b\n"
+                 "2:"
+                 : [chain] "=&s"(chain), [cur] "=&s"(cur)
+                 : [ok] "s"(okmask), [next] "v"(nextlane)
+                 : "scc");
     if (chain == 0ull) return 0;
 
     const bool on = ((chain >> lane) & 1ull) != 0ull;
