@@ -115,6 +115,12 @@ int pq_bitunpack64(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, size_
                               encoding/delta-binary-packed-decoder.go:250-322) */
 #define PQ_KIND_PAGE_V1 6  /* dataPageReaderV1.read + ReadValues (layout/page-v1.go:40-116) */
 #define PQ_KIND_PAGE_V2 7  /* dataPageReaderV2.read + ReadValues (layout/page-v2.go:42-149) */
+#define PQ_KIND_PLAIN 8    /* Int32/Int64/Float/DoublePlainDecoder.DecodeValues (types/int32.go:56-72,
+                              types/int64.go:56-72, types/float.go:67-79, types/double.go:68-80):
+                              elem_size (4 or 8) little-endian bytes per value */
+#define PQ_KIND_BOOL_PLAIN 9 /* BooleanPlainDecoder.DecodeValues on a fresh decoder
+                              (types/boolean.go:59-104): bit j of byte i is value 8 i + j,
+                              written as the int32 0 / 1 that unpackByte yields */
 
 #define PQ_FLAG_LENGTH_PREFIXED 1u /* HYBRID/LEVELS: InitSize (u32 LE length first) */
 #define PQ_FLAG_LEVELS_CONST 2u    /* LEVELS: ConstDecoder(0) (layout/chunk.go:111-124) */
@@ -137,8 +143,9 @@ typedef struct pq_page_desc {
     uint32_t max_def;     /* pages: max definition level; LEVELS: the stream's max level */
     uint32_t rep_len;     /* PAGE_V2: RepetitionLevelsByteLength */
     uint32_t def_len;     /* PAGE_V2: DefinitionLevelsByteLength */
-    uint32_t value_kind;  /* pages: PQ_KIND_DICT, PQ_KIND_DELTA32 or PQ_KIND_DELTA64 */
-    uint32_t elem_size;   /* DICT: bytes per dictionary entry (4 or 8) */
+    uint32_t value_kind;  /* pages: PQ_KIND_DICT, PQ_KIND_DELTA32, PQ_KIND_DELTA64, PQ_KIND_PLAIN
+                             or PQ_KIND_BOOL_PLAIN */
+    uint32_t elem_size;   /* DICT: bytes per dictionary entry (4 or 8); PLAIN: bytes per value */
     uint32_t dict_len;    /* DICT: number of dictionary entries */
     uint32_t reserved;
 } pq_page_desc;
@@ -198,6 +205,12 @@ int pq_delta_decode32(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t 
                       uint32_t *n_decoded, uint64_t *consumed);
 int pq_delta_decode64(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n, int64_t *dst,
                       uint32_t *n_decoded, uint64_t *consumed);
+/* plain:  Int32/Int64/Float/DoublePlainDecoder.DecodeValues(dest[:n]), elem_size 4 or 8
+ * bool:   BooleanPlainDecoder.DecodeValues(dest[:n]) of a fresh decoder, int32 0 / 1 per value */
+int pq_plain_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t elem_size, uint32_t n,
+                    void *dst, uint32_t *n_decoded, uint64_t *consumed);
+int pq_bool_plain_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n, int32_t *dst,
+                         uint32_t *n_decoded, uint64_t *consumed);
 
 #ifdef __cplusplus
 }

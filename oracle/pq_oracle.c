@@ -737,6 +737,60 @@ int pqo_delta_decode64(const uint8_t *src, size_t src_len, uint32_t n, int64_t *
 }
 
 /* ------------------------------------------------------------------------- */
+/* PLAIN fixed width and BOOLEAN PLAIN                                           */
+
+/* Int32/Int64/Float/DoublePlainDecoder.DecodeValues (types/int32.go:56-72,
+ * types/int64.go:56-72, types/float.go:67-79, types/double.go:68-80): one
+ * binary.Read of elem_size little-endian bytes per value; nothing left is io.EOF,
+ * a partial value io.ErrUnexpectedEOF. */
+static int plain_next(rd_t *r, uint32_t elem_size, uint8_t *out)
+{
+    size_t rem = r->len - r->pos;
+    if (rem == 0) return PQO_EOF;
+    if (rem < elem_size) {
+        r->pos = r->len;
+        return PQO_UNEXPECTED_EOF;
+    }
+    memcpy(out, r->p + r->pos, elem_size);
+    r->pos += elem_size;
+    return PQO_OK;
+}
+
+int pqo_plain_decode(const uint8_t *src, size_t src_len, uint32_t elem_size, uint32_t n, void *dst,
+                     uint32_t *n_decoded, uint64_t *consumed)
+{
+    rd_t r = {src, src_len, 0};
+    int st = PQO_OK;
+    uint32_t i = 0;
+    for (; i < n; i++) {
+        st = plain_next(&r, elem_size, (uint8_t *)dst + (size_t)i * elem_size);
+        if (st != PQO_OK) break;
+    }
+    if (n_decoded) *n_decoded = i;
+    if (consumed) *consumed = r.pos;
+    return st;
+}
+
+/* BooleanPlainDecoder.DecodeValues on a fresh decoder (types/boolean.go:59-104): one
+ * byte per 8 values, bit j of it is value j (unpackByte); a missing byte is io.EOF and
+ * the count returned is the index of the group that could not be read. */
+int pqo_bool_plain_decode(const uint8_t *src, size_t src_len, uint32_t n, int32_t *dst,
+                          uint32_t *n_decoded, uint64_t *consumed)
+{
+    rd_t r = {src, src_len, 0};
+    int st = PQO_OK;
+    uint32_t i = 0;
+    for (; i < n; i += 8) {
+        if (r.pos >= r.len) { st = PQO_EOF; break; }
+        uint8_t b = r.p[r.pos++];
+        for (uint32_t j = 0; j < 8 && i + j < n; j++) dst[i + j] = (b >> j) & 1;
+    }
+    if (n_decoded) *n_decoded = i < n ? i : n;
+    if (consumed) *consumed = r.pos;
+    return st;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Data pages: layout/page-v1.go:40-116, layout/page-v2.go:42-149              */
 
 static void make_level_decoders(uint32_t max_rep, uint32_t max_def, level_dec_t *rep,
@@ -800,6 +854,8 @@ void pqo_page_read(const pqo_page_in *in, int32_t *rep, int32_t *def, void *valu
     case PQO_VALUES_DICT: st = dict_init(&dict, &r); break;
     case PQO_VALUES_DELTA32: st = delta_init(&delta, &r, 0); break;
     case PQO_VALUES_DELTA64: st = delta_init(&delta, &r, 1); break;
+    case PQO_VALUES_PLAIN:   /* Init only keeps the reader (types/int32.go:50-53) */
+    case PQO_VALUES_BOOL_PLAIN: st = PQO_OK; break;
     default: st = PQO_NOT_INITIALIZED; break;
     }
     if (st != PQO_OK) {
@@ -826,6 +882,10 @@ void pqo_page_read(const pqo_page_in *in, int32_t *rep, int32_t *def, void *valu
         if (in->value_kind == PQO_VALUES_DICT) {
             st = dict_decode_values(&dict, (const uint8_t *)in->dict, in->dict_len, in->elem_size,
                                     nn, (uint8_t *)values, &cnt);
+        } else if (in->value_kind == PQO_VALUES_PLAIN) {
+            st = pqo_plain_decode(r.p + r.pos, r.len - r.pos, in->elem_size, nn, values, &cnt, NULL);
+        } else if (in->value_kind == PQO_VALUES_BOOL_PLAIN) {
+            st = pqo_bool_plain_decode(r.p + r.pos, r.len - r.pos, nn, (int32_t *)values, &cnt, NULL);
         } else {
             int is64 = in->value_kind == PQO_VALUES_DELTA64;
             for (; cnt < nn; cnt++) {

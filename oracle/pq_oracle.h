@@ -63,7 +63,9 @@ enum pqo_stage {
 enum pqo_value_kind {
     PQO_VALUES_DICT = 1,    /* types.DictDecoder, elem_size bytes per dictionary entry */
     PQO_VALUES_DELTA32 = 2, /* types.Int32DeltaBPDecoder */
-    PQO_VALUES_DELTA64 = 3  /* types.Int64DeltaBPDecoder */
+    PQO_VALUES_DELTA64 = 3, /* types.Int64DeltaBPDecoder */
+    PQO_VALUES_PLAIN = 4,   /* Int32/Int64/Float/DoublePlainDecoder, elem_size bytes per value */
+    PQO_VALUES_BOOL_PLAIN = 5 /* BooleanPlainDecoder, one int32 0/1 per value */
 };
 
 /* ---- fixed-width bit packing (encoding/bitpacking32.go, bitpacking64.go) ---- */
@@ -111,6 +113,15 @@ int pqo_delta_decode32(const uint8_t *src, size_t src_len, uint32_t n, int32_t *
 int pqo_delta_decode64(const uint8_t *src, size_t src_len, uint32_t n, int64_t *dst,
                        uint32_t *n_decoded, uint64_t *consumed, uint32_t *values_count,
                        int *init_status);
+
+/* ---- PLAIN fixed width (types/int32.go:56-72, types/int64.go:56-72, types/float.go:67-79,
+ *      types/double.go:68-80) and BOOLEAN PLAIN (types/boolean.go:59-104; values as the
+ *      int32 0/1 that unpackByte yields).  Pinned by the decoder vectors of
+ *      types/float_test.go and types/double_test.go; the boolean decoder has no reference test. ---- */
+int pqo_plain_decode(const uint8_t *src, size_t src_len, uint32_t elem_size, uint32_t n, void *dst,
+                     uint32_t *n_decoded, uint64_t *consumed);
+int pqo_bool_plain_decode(const uint8_t *src, size_t src_len, uint32_t n, int32_t *dst,
+                          uint32_t *n_decoded, uint64_t *consumed);
 
 /* ---- data pages (layout/page-v1.go:40-116, layout/page-v2.go:42-149) ---- */
 typedef struct pqo_page_in {

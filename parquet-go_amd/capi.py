@@ -20,6 +20,7 @@ INVALID_STREAM, PAGE_VALUES_FAILED = 14, 15
 ERR_BAD_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_OUT_OF_RANGE = 100, 101, 102, 103
 
 KIND_HYBRID, KIND_DICT, KIND_LEVELS, KIND_DELTA32, KIND_DELTA64, KIND_PAGE_V1, KIND_PAGE_V2 = range(1, 8)
+KIND_PLAIN, KIND_BOOL_PLAIN = 8, 9
 FLAG_LENGTH_PREFIXED, FLAG_LEVELS_CONST, FLAG_NO_INIT = 1, 2, 4
 OPT_DELTA_WAVE_MIN_PAGES = 1
 OPT_HYBRID_WAVE_MIN_PAGES = 2
@@ -32,7 +33,7 @@ EXPORTS = [
     "pq_version", "pq_bitunpack32_dev", "pq_bitunpack64_dev", "pq_bitunpack32", "pq_bitunpack64",
     "pq_plan_create", "pq_plan_run", "pq_plan_results", "pq_plan_destroy", "pq_decode_pages",
     "pq_hybrid_decode", "pq_dict_decode", "pq_levels_decode", "pq_delta_decode32",
-    "pq_delta_decode64",
+    "pq_delta_decode64", "pq_plain_decode", "pq_bool_plain_decode",
 ]
 
 
@@ -115,6 +116,10 @@ def load():
         for name in ("pq_delta_decode32", "pq_delta_decode64"):
             getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
                                            C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        lib.pq_plain_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
+                                        C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        lib.pq_bool_plain_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
+                                             C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         _lib = lib
     return _lib
 
@@ -219,6 +224,25 @@ class Context:
                             C.byref(cons)), "delta")
         return dict(status=st, values=out[:nd.value].copy(), n_decoded=nd.value,
                     consumed=cons.value)
+
+    def plain_decode(self, src, n, dtype):
+        """Int32/Int64/Float/DoublePlainDecoder.DecodeValues(dest[:n])."""
+        s = _np_u8(src)
+        dt = np.dtype(dtype)
+        out = np.zeros(max(n, 1), dtype=dt)
+        nd, cons = C.c_uint32(0), C.c_uint64(0)
+        st = self._check(self._lib.pq_plain_decode(self._h, _ptr(s), s.size, dt.itemsize, int(n), _ptr(out),
+                                                   C.byref(nd), C.byref(cons)), "plain")
+        return dict(status=st, values=out[:nd.value].copy(), n_decoded=nd.value, consumed=cons.value)
+
+    def bool_plain_decode(self, src, n):
+        """BooleanPlainDecoder.DecodeValues(dest[:n]) of a fresh decoder; int32 0 / 1 per value."""
+        s = _np_u8(src)
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        nd, cons = C.c_uint32(0), C.c_uint64(0)
+        st = self._check(self._lib.pq_bool_plain_decode(self._h, _ptr(s), s.size, int(n), _ptr(out),
+                                                        C.byref(nd), C.byref(cons)), "bool")
+        return dict(status=st, values=out[:nd.value].copy(), n_decoded=nd.value, consumed=cons.value)
 
     def decode_pages(self, descs, src, values_bytes=0, levels_bytes=0, dictionary=None):
         """descs: numpy array of DESC_DTYPE.  Returns (results, values_u8, levels_i32)."""

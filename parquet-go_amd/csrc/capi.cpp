@@ -65,7 +65,9 @@ int group_of(uint32_t kind)
     switch (kind) {
     case PQ_KIND_HYBRID:
     case PQ_KIND_DICT:
-    case PQ_KIND_LEVELS: return 0;
+    case PQ_KIND_LEVELS:
+    case PQ_KIND_PLAIN:
+    case PQ_KIND_BOOL_PLAIN: return 0;
     case PQ_KIND_DELTA32: return 1;
     case PQ_KIND_DELTA64: return 2;
     case PQ_KIND_PAGE_V1:
@@ -84,6 +86,8 @@ uint32_t value_size(const pq_page_desc &d)
     case PQ_KIND_DICT: return d.elem_size;
     case PQ_KIND_DELTA32: return 4;
     case PQ_KIND_DELTA64: return 8;
+    case PQ_KIND_PLAIN: return d.elem_size;
+    case PQ_KIND_BOOL_PLAIN: return 4;
     default: return 0;
     }
 }
@@ -95,8 +99,10 @@ int validate(const pq_page_desc &d)
     if (d.src_len > 0x7fffffffffffull) return PQ_ERR_BAD_ARGUMENT;
     const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
     if (page && d.value_kind != PQ_KIND_DICT && d.value_kind != PQ_KIND_DELTA32 &&
-        d.value_kind != PQ_KIND_DELTA64)
+        d.value_kind != PQ_KIND_DELTA64 && d.value_kind != PQ_KIND_PLAIN && d.value_kind != PQ_KIND_BOOL_PLAIN)
         return PQ_ERR_BAD_ARGUMENT;
+    const bool plain = d.kind == PQ_KIND_PLAIN || (page && d.value_kind == PQ_KIND_PLAIN);
+    if (plain && d.elem_size != 4 && d.elem_size != 8) return PQ_ERR_BAD_ARGUMENT;
     const bool dict = d.kind == PQ_KIND_DICT || (page && d.value_kind == PQ_KIND_DICT);
     if (dict) {
         if (d.elem_size != 4 && d.elem_size != 8) return PQ_ERR_BAD_ARGUMENT;
@@ -553,6 +559,28 @@ static int delta_host(pq_ctx *ctx, uint32_t kind, const uint8_t *src, size_t src
     if (n_decoded) *n_decoded = r.n_decoded;
     if (consumed) *consumed = r.consumed;
     return r.status;
+}
+
+int pq_plain_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t elem_size, uint32_t n, void *dst,
+                    uint32_t *n_decoded, uint64_t *consumed)
+{
+    pq_page_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.kind = PQ_KIND_PLAIN;
+    d.n_values = n;
+    d.elem_size = elem_size;
+    pq_page_result r;
+    const int st = one_page(ctx, d, src, src_len, dst, (size_t)n * elem_size, nullptr, 0, nullptr, 0, &r);
+    if (st != PQ_OK) return st;
+    if (n_decoded) *n_decoded = r.n_decoded;
+    if (consumed) *consumed = r.consumed;
+    return r.status;
+}
+
+int pq_bool_plain_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n, int32_t *dst,
+                         uint32_t *n_decoded, uint64_t *consumed)
+{
+    return delta_host(ctx, PQ_KIND_BOOL_PLAIN, src, src_len, n, dst, 4, n_decoded, consumed);
 }
 
 int pq_delta_decode32(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n, int32_t *dst,

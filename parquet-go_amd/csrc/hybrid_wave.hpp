@@ -442,11 +442,13 @@ __device__ __forceinline__ void hw_expand(HybridWaveLds &L, const HwSink<OutT> &
 }
 
 // Decode n values of the stream [S, S + len) at bit width w into dst with ONE wave.
-// Modes as in hybrid_stream.  `dict` may point to LDS or global memory.
+// Modes as in hybrid_stream.  `dict` may point to LDS or global memory.  raw_groups != 0: the
+// stream has no run headers at all, it is that many bit-packed groups (PLAIN fixed-width values
+// are groups of width 32, BOOLEAN PLAIN bytes groups of width 1).
 template <int MODE, typename OutT>
 __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint8_t *S, int64_t len, uint32_t w,
                                                     uint32_t n, OutT *dst, const OutT *dict, uint32_t dict_len,
-                                                    uint32_t max_level, int lane)
+                                                    uint32_t max_level, int lane, uint32_t raw_groups = 0)
 {
     HybridResult res{PQ_OK, 0, 0, 0};
     const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(dst) / sizeof(OutT)) & 3u);
@@ -480,8 +482,8 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
     HwState st;
     st.o = (uint32_t)(0 - c0);
     st.v = 0;
-    st.pend = 0;
-    st.pcount = 0;
+    st.pend = raw_groups != 0u ? 2u : 0u;
+    st.pcount = raw_groups;
     st.pvalue = 0;
     st.status = PQ_OK;
 

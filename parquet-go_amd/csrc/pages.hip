@@ -90,6 +90,51 @@ __device__ __forceinline__ bool cache_dict(uint32_t *ldict, const uint8_t *gdict
     return true;
 }
 
+// PLAIN fixed-width values (types/int32.go:56-72, types/int64.go:56-72, types/float.go:67-79,
+// types/double.go:68-80): n values of es little-endian bytes; what is missing is io.EOF, a
+// partial value io.ErrUnexpectedEOF.  Result fields only; the copy is done by the callers.
+__device__ __forceinline__ HybridResult plain_result(int64_t len, uint32_t n, uint32_t es, uint32_t *n_ok)
+{
+    const uint64_t have = len > 0 ? (uint64_t)len / es : 0u;
+    *n_ok = have < (uint64_t)n ? (uint32_t)have : n;
+    HybridResult r{PQ_OK, *n_ok, 0, (uint64_t)*n_ok * es};
+    if (*n_ok < n) {
+        const bool partial = len > 0 && ((uint64_t)len % es) != 0u;
+        r.status = partial ? PQ_UNEXPECTED_EOF : PQ_EOF;
+        if (partial) r.consumed = (uint64_t)len;
+    }
+    return r;
+}
+
+// BOOLEAN PLAIN on a fresh decoder (types/boolean.go:59-104): one byte per 8 values; a missing
+// byte is io.EOF and the count is the index of the group that could not be read.
+__device__ __forceinline__ HybridResult bool_result(int64_t len, uint32_t n, uint32_t *n_ok)
+{
+    const uint64_t have = len > 0 ? 8u * (uint64_t)len : 0u;
+    *n_ok = have < (uint64_t)n ? (uint32_t)have : n;
+    HybridResult r{*n_ok < n ? PQ_EOF : PQ_OK, *n_ok, 0, (uint64_t)((*n_ok + 7u) >> 3)};
+    return r;
+}
+
+// The same two by a whole workgroup, element by element (the fallback kernels).
+__device__ __forceinline__ HybridResult plain_values_wg(const uint8_t *S, int64_t len, uint32_t n, uint32_t es,
+                                                        uint32_t *dst)
+{
+    uint32_t n_ok;
+    const HybridResult r = plain_result(len, n, es, &n_ok);
+    const uint32_t words = n_ok * (es / 4u);
+    for (uint32_t i = threadIdx.x; i < words; i += kWG) dst[i] = load_le32(S + 4u * (size_t)i);
+    return r;
+}
+
+__device__ __forceinline__ HybridResult bool_values_wg(const uint8_t *S, int64_t len, uint32_t n, uint32_t *dst)
+{
+    uint32_t n_ok;
+    const HybridResult r = bool_result(len, n, &n_ok);
+    for (uint32_t i = threadIdx.x; i < n_ok; i += kWG) dst[i] = (S[i >> 3] >> (i & 7u)) & 1u;
+    return r;
+}
+
 // DictDecoder over [S, S+len): bit-width byte, then an unprefixed hybrid stream
 // (types/dict.go:66-117).  init_status reports Init alone.
 template <typename OutT>
@@ -164,6 +209,10 @@ __global__ __launch_bounds__(kWG) void stream_pages_kernel(const pq_page_desc *_
                 r.consumed = (uint64_t)len;
             }
         }
+    } else if (d.kind == PQ_KIND_PLAIN) {
+        r = plain_values_wg(S, len, n, d.elem_size, reinterpret_cast<uint32_t *>(buf.values + d.dst_off));
+    } else if (d.kind == PQ_KIND_BOOL_PLAIN) {
+        r = bool_values_wg(S, len, n, reinterpret_cast<uint32_t *>(buf.values + d.dst_off));
     } else { // PQ_KIND_DICT
         const uint8_t *gd = buf.dict + d.dict_off;
         const uint32_t dbytes = d.dict_len * d.elem_size;
@@ -412,6 +461,13 @@ __device__ __forceinline__ void data_page_wg(PageShared &sh, uint32_t *ldict, co
                                        reinterpret_cast<const uint32_t *>(ldict), in_lds, d.dict_len, &v_init);
         v_status = vr.status;
         v_count = vr.n_decoded;
+    } else if (d.value_kind == PQ_KIND_PLAIN || d.value_kind == PQ_KIND_BOOL_PLAIN) {
+        // Init only keeps the reader (types/int32.go:50-53)
+        uint32_t *vdst = reinterpret_cast<uint32_t *>(buf.values + d.dst_off);
+        const HybridResult vr = d.value_kind == PQ_KIND_PLAIN ? plain_values_wg(VS, vlen, nvals, d.elem_size, vdst)
+                                                              : bool_values_wg(VS, vlen, nvals, vdst);
+        v_status = vr.status;
+        v_count = vr.n_decoded;
     } else {
         DeltaResult vr;
         if (d.value_kind == PQ_KIND_DELTA64)
@@ -532,6 +588,29 @@ __device__ __forceinline__ HybridResult dict_values_wave(HybridWaveLds &L, const
     return r;
 }
 
+// PLAIN values are headerless groups of width 32 (an 8-byte value is two of them), BOOLEAN
+// PLAIN bytes headerless groups of width 1: both ride the bulk path of hybrid_wave.
+__device__ __forceinline__ HybridResult plain_values_wave(HybridWaveLds &L, const uint8_t *S, int64_t len, uint32_t n,
+                                                          uint32_t es, uint32_t *dst, int lane)
+{
+    uint32_t n_ok;
+    const HybridResult r = plain_result(len, n, es, &n_ok);
+    const uint32_t words = n_ok * (es / 4u);
+    if (words != 0u)
+        (void)hybrid_wave<HY_RAW, uint32_t>(L, S, len, 32u, words, dst, nullptr, 0, 0, lane, (words + 7u) >> 3);
+    return r;
+}
+
+__device__ __forceinline__ HybridResult bool_values_wave(HybridWaveLds &L, const uint8_t *S, int64_t len, uint32_t n,
+                                                         uint32_t *dst, int lane)
+{
+    uint32_t n_ok;
+    const HybridResult r = bool_result(len, n, &n_ok);
+    if (n_ok != 0u)
+        (void)hybrid_wave<HY_RAW, uint32_t>(L, S, len, 1u, n_ok, dst, nullptr, 0, 0, lane, (n_ok + 7u) >> 3);
+    return r;
+}
+
 __global__ __launch_bounds__(kWG) void stream_wave_kernel(const pq_page_desc *__restrict__ descs,
                                                           const uint32_t *__restrict__ ids, uint32_t count,
                                                           PageBuffers buf, pq_page_result *__restrict__ results,
@@ -574,6 +653,10 @@ __global__ __launch_bounds__(kWG) void stream_wave_kernel(const pq_page_desc *__
             else if (levels && !sec.no_reader)
                 r.consumed = (uint64_t)len;
         }
+    } else if (d.kind == PQ_KIND_PLAIN) {
+        r = plain_values_wave(L, S, len, n, d.elem_size, reinterpret_cast<uint32_t *>(buf.values + d.dst_off), lane);
+    } else if (d.kind == PQ_KIND_BOOL_PLAIN) {
+        r = bool_values_wave(L, S, len, n, reinterpret_cast<uint32_t *>(buf.values + d.dst_off), lane);
     } else { // PQ_KIND_DICT
         WaveDict wd{buf.dict + d.dict_off, ldict};
         int32_t init_status;
@@ -721,6 +804,13 @@ __global__ __launch_bounds__(kWG) void data_wave_kernel(const pq_page_desc *__re
         else
             vr = dict_values_wave<uint32_t>(L, VS, vlen, nvals, reinterpret_cast<uint32_t *>(buf.values + d.dst_off), wd,
                                             d.dict_len, &v_init, lane);
+        v_status = vr.status;
+        v_count = vr.n_decoded;
+    } else if (d.value_kind == PQ_KIND_PLAIN || d.value_kind == PQ_KIND_BOOL_PLAIN) {
+        uint32_t *vdst = reinterpret_cast<uint32_t *>(buf.values + d.dst_off);
+        const HybridResult vr = d.value_kind == PQ_KIND_PLAIN
+                                    ? plain_values_wave(L, VS, vlen, nvals, d.elem_size, vdst, lane)
+                                    : bool_values_wave(L, VS, vlen, nvals, vdst, lane);
         v_status = vr.status;
         v_count = vr.n_decoded;
     } else {

@@ -390,6 +390,68 @@ private:
 using Int32DeltaBPDecoder = DeltaBPDecoder<int32_t>;
 using Int64DeltaBPDecoder = DeltaBPDecoder<int64_t>;
 
+// ---- types.Int32/Int64/Float/DoublePlainDecoder (types/int32.go:45-72, types/int64.go:45-72,
+//      types/float.go:56-79, types/double.go:57-80) and BooleanPlainDecoder (types/boolean.go:46-104) ----
+template <typename T>
+class PlainDecoder {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "int32, int64, float or double");
+
+public:
+    explicit PlainDecoder(Device &dev) : dev_(dev) {}
+    Error Init(Reader &r)
+    {
+        reader_ = &r;
+        return Error();
+    }
+    // (count, err): io.EOF when values are missing, io.ErrUnexpectedEOF for a partial one
+    std::pair<int, Error> DecodeValues(T *dest, uint32_t n)
+    {
+        if (!reader_) return {0, Error(PQ_NOT_INITIALIZED)};
+        uint32_t count = 0;
+        uint64_t consumed = 0;
+        int st = pq_plain_decode(dev_.ctx(), reader_->cursor(), reader_->Len(), sizeof(T), n, dest, &count, &consumed);
+        check_library(st, "pq_plain_decode");
+        reader_->advance((size_t)consumed);
+        return {(int)count, Error(st)};
+    }
+
+private:
+    Device &dev_;
+    Reader *reader_ = nullptr;
+};
+using Int32PlainDecoder = PlainDecoder<int32_t>;
+using Int64PlainDecoder = PlainDecoder<int64_t>;
+using FloatPlainDecoder = PlainDecoder<float>;
+using DoublePlainDecoder = PlainDecoder<double>;
+
+// One DecodeValues call on a fresh decoder: the bits left over in the last byte are dropped
+// here, where the reference keeps them for its next call (types/boolean.go:62-70).
+class BooleanPlainDecoder {
+public:
+    explicit BooleanPlainDecoder(Device &dev) : dev_(dev) {}
+    Error Init(Reader &r)
+    {
+        reader_ = &r;
+        return Error();
+    }
+    std::pair<int, Error> DecodeValues(bool *dest, uint32_t n)
+    {
+        if (!reader_) return {0, Error(PQ_NOT_INITIALIZED)};
+        std::vector<int32_t> tmp(n ? n : 1);
+        uint32_t count = 0;
+        uint64_t consumed = 0;
+        int st = pq_bool_plain_decode(dev_.ctx(), reader_->cursor(), reader_->Len(), n, tmp.data(), &count, &consumed);
+        check_library(st, "pq_bool_plain_decode");
+        for (uint32_t i = 0; i < count; ++i) dest[i] = tmp[i] == 1;
+        reader_->advance((size_t)consumed);
+        return {(int)count, Error(st)};
+    }
+
+private:
+    Device &dev_;
+    Reader *reader_ = nullptr;
+};
+
 // ---- layout.decodePackedArray (layout/helpers.go:68-90) ------------------------------------
 // levelDecoder = a Decoder that knows its maximum level (layout/level-decoder.go:5-18).
 struct LevelDecoder {
@@ -430,7 +492,8 @@ inline PackedLevels decodePackedArray(LevelDecoder d, int count)
 // ---- data pages (layout/page-v1.go:40-116, layout/page-v2.go:42-149) --------------------------
 struct ColumnSpec {
     uint16_t maxR = 0, maxD = 0;
-    uint32_t valueKind = PQ_KIND_DICT;  // PQ_KIND_DICT (RLE_DICTIONARY), PQ_KIND_DELTA32, PQ_KIND_DELTA64
+    uint32_t valueKind = PQ_KIND_DICT;  // PQ_KIND_DICT (RLE_DICTIONARY), PQ_KIND_DELTA32, PQ_KIND_DELTA64,
+                                        // PQ_KIND_PLAIN, PQ_KIND_BOOL_PLAIN (elemSize 4: int32 0 / 1)
     uint32_t elemSize = 4;              // bytes per value
     const void *dict = nullptr;         // PLAIN-decoded dictionary page (DICT only)
     uint32_t dictLen = 0;

@@ -15,6 +15,7 @@ Sources (paths relative to the reference root):
   encoding/delta-binary-packed-decoder_test.go:29-153,157-293,
   encoding/delta-binary-packed-encoder_test.go:118-167,274-326 -> delta.json
   encoding/packed-array_test.go:211-229    -> packed_array.json
+  types/float_test.go:120-171, types/double_test.go:120-171 -> plain.json
 """
 import json
 import os
@@ -121,6 +122,20 @@ def main():
               "w": 3, "values": [0, 1, 2, 3, 4, 5, 6, 7],
               "bytes": [0b10001000, 0b11000110, 0b11111010]}
     json.dump(packed, open(os.path.join(OUT, "packed_array.json"), "w"))
+    # PLAIN decoder vectors: the byte strings are read from the test sources, the expected
+    # values and counts are what the tests assert (1., 2., 3.; two values then io.EOF).
+    plain = {"source": "types/float_test.go:120-171, types/double_test.go:120-171", "vectors": []}
+    for name, dtype in (("float_test.go", "float32"), ("double_test.go", "float64")):
+        text = open(os.path.join(REF, "types", name)).read()
+        dec = text[text.index("PlainDecoder_DecodeValues(t"):]
+        full = _ints(re.search(r"memory\.NewWriter\(\[\]byte\{([^}]*)\}\)", dec).group(1))
+        short_src = dec[dec.index("DecodeValues_NotEnoughValues"):]
+        short = _ints(re.search(r"memory\.NewWriter\(\[\]byte\{([^}]*)\}\)", short_src).group(1))
+        plain["vectors"].append({"dtype": dtype, "data": full, "n": 3, "values": [1.0, 2.0, 3.0],
+                                 "status": "ok", "count": 3})
+        plain["vectors"].append({"dtype": dtype, "data": short, "n": 3, "values": [1.0, 2.0],
+                                 "status": "eof", "count": 2})
+    json.dump(plain, open(os.path.join(OUT, "plain.json"), "w"))
     print("wrote fixtures: %d int32 + %d int64 bit-pack vectors" % (len(v32), len(v64)))
 
 

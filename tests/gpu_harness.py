@@ -23,20 +23,25 @@ class Case:
         self.def_len = kw.get("def_len", 0)
         self.value_kind = kw.get("value_kind", 0)
         self.dictionary = kw.get("dictionary", None)
+        self.plain_dtype = np.dtype(kw["plain_dtype"]) if "plain_dtype" in kw else None  # PLAIN values
         self.src_len = kw.get("src_len", None)  # override (e.g. truncate without copying)
 
     def elem_size(self):
         k = self.value_kind if self.kind in (capi.KIND_PAGE_V1, capi.KIND_PAGE_V2) else self.kind
         if k == capi.KIND_DICT:
             return self.dictionary.dtype.itemsize
-        return {capi.KIND_HYBRID: 4, capi.KIND_DELTA32: 4, capi.KIND_DELTA64: 8}.get(k, 0)
+        if k == capi.KIND_PLAIN:
+            return self.plain_dtype.itemsize
+        return {capi.KIND_HYBRID: 4, capi.KIND_DELTA32: 4, capi.KIND_DELTA64: 8, capi.KIND_BOOL_PLAIN: 4}.get(k, 0)
 
     def value_dtype(self):
         k = self.value_kind if self.kind in (capi.KIND_PAGE_V1, capi.KIND_PAGE_V2) else self.kind
         if k == capi.KIND_DICT:
             return self.dictionary.dtype
-        return {capi.KIND_HYBRID: np.int32, capi.KIND_DELTA32: np.int32,
-                capi.KIND_DELTA64: np.int64}.get(k, np.uint8)
+        if k == capi.KIND_PLAIN:
+            return self.plain_dtype
+        return {capi.KIND_HYBRID: np.int32, capi.KIND_DELTA32: np.int32, capi.KIND_DELTA64: np.int64,
+                capi.KIND_BOOL_PLAIN: np.int32}.get(k, np.uint8)
 
 
 def run_cases(ctx, cases, seed=0):
@@ -61,6 +66,8 @@ def run_cases(ctx, cases, seed=0):
         d["max_rep"], d["max_def"] = c.max_rep, c.max_def
         d["rep_len"], d["def_len"] = c.rep_len, c.def_len
         d["value_kind"] = c.value_kind
+        if c.plain_dtype is not None:
+            d["elem_size"] = c.plain_dtype.itemsize
         es = c.elem_size()
         if es:
             val_pos += es * int(rng.integers(0, 5))       # vary 16-byte alignment of outputs

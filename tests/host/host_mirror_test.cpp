@@ -275,6 +275,92 @@ static void TestPackedArray()
     }
 }
 
+// ---- types/float_test.go:120-171, types/double_test.go:120-171 -----------------------------------
+static void TestPlainDecoders(Device &dev)
+{
+    {  // FloatPlainDecoder_DecodeValues and _NotEnoughValues
+        std::vector<uint8_t> data = {0x00, 0x00, 0x80, 0x3f, 0x00, 0x00, 0x00, 0x40, 0x00, 0x00, 0x40, 0x40};
+        Reader r(data);
+        FloatPlainDecoder d(dev);
+        CHECK(!d.Init(r));
+        float dest[3] = {0, 0, 0};
+        auto res = d.DecodeValues(dest, 3);
+        CHECK(!res.second);
+        CHECK_EQ(res.first, 3);
+        CHECK(dest[0] == 1.f && dest[1] == 2.f && dest[2] == 3.f);
+        data.resize(8);
+        Reader r2(data);
+        CHECK(!d.Init(r2));
+        float d2[3] = {0, 0, 0};
+        res = d.DecodeValues(d2, 3);
+        CHECK(res.second.is(PQ_EOF));
+        CHECK_EQ(res.first, 2);
+        CHECK(d2[0] == 1.f && d2[1] == 2.f && d2[2] == 0.f);
+    }
+    {  // DoublePlainDecoder_DecodeValues and _NotEnoughValues
+        std::vector<uint8_t> data = {0, 0, 0, 0, 0, 0, 0xF0, 0x3F, 0, 0, 0, 0, 0, 0, 0, 0x40, 0, 0, 0, 0, 0, 0, 8, 0x40};
+        Reader r(data);
+        DoublePlainDecoder d(dev);
+        CHECK(!d.Init(r));
+        double dest[3] = {0, 0, 0};
+        auto res = d.DecodeValues(dest, 3);
+        CHECK(!res.second);
+        CHECK_EQ(res.first, 3);
+        CHECK(dest[0] == 1. && dest[1] == 2. && dest[2] == 3.);
+        CHECK_EQ(r.Len(), 0);
+        data.resize(16);
+        Reader r2(data);
+        CHECK(!d.Init(r2));
+        res = d.DecodeValues(dest, 3);
+        CHECK(res.second.is(PQ_EOF));
+        CHECK_EQ(res.first, 2);
+    }
+    {  // int32 / int64 against the oracle, with a partial last value
+        const uint32_t n = 70001;
+        std::vector<uint8_t> s((size_t)n * 8 - 3);
+        for (auto &b : s) b = (uint8_t)rnd();
+        Reader r(s);
+        Int64PlainDecoder d(dev);
+        CHECK(!d.Init(r));
+        std::vector<int64_t> out(n), ref(n);
+        auto res = d.DecodeValues(out.data(), n);
+        uint32_t nd = 0;
+        uint64_t consumed = 0;
+        int ost = pqo_plain_decode(s.data(), s.size(), 8, n, ref.data(), &nd, &consumed);
+        CHECK_EQ(res.second.status, ost);
+        CHECK(res.second.is(PQ_UNEXPECTED_EOF));
+        CHECK_EQ(res.first, nd);
+        CHECK(std::equal(out.begin(), out.begin() + nd, ref.begin()));
+        Reader r32(s);
+        Int32PlainDecoder d32(dev);
+        CHECK(!d32.Init(r32));
+        std::vector<int32_t> o32(1000), r32v(1000);
+        auto res32 = d32.DecodeValues(o32.data(), 1000);
+        CHECK(!res32.second);
+        CHECK_EQ(pqo_plain_decode(s.data(), s.size(), 4, 1000, r32v.data(), &nd, &consumed), 0);
+        CHECK(o32 == r32v);
+        CHECK_EQ(s.size() - r32.Len(), 4000);
+    }
+    {  // BooleanPlainDecoder: bit j of byte i is value 8 i + j
+        std::vector<uint8_t> s = {0xA5, 0x01};
+        Reader r(s);
+        BooleanPlainDecoder d(dev);
+        CHECK(!d.Init(r));
+        bool dest[12];
+        auto res = d.DecodeValues(dest, 12);
+        CHECK(!res.second);
+        CHECK_EQ(res.first, 12);
+        const bool want[12] = {1, 0, 1, 0, 0, 1, 0, 1, 1, 0, 0, 0};
+        for (int i = 0; i < 12; ++i) CHECK_EQ(dest[i], want[i]);
+        Reader r2(s);
+        CHECK(!d.Init(r2));
+        bool big[40];
+        res = d.DecodeValues(big, 40);
+        CHECK(res.second.is(PQ_EOF));
+        CHECK_EQ(res.first, 16);
+    }
+}
+
 // ---- types.DictDecoder (no reference test; checked against the oracle) ---------------------------
 template <typename T>
 static void TestDictDecoder(Device &dev)
@@ -570,6 +656,7 @@ int main()
         {"TestDeltaBinaryPackDecoder32", [&] { TestDeltaBinaryPackDecoder<int32_t>(dev); }},
         {"TestDeltaBinaryPackDecoder64", [&] { TestDeltaBinaryPackDecoder<int64_t>(dev); }},
         {"TestPackedArray", [&] { TestPackedArray(); }},
+        {"TestPlainDecoders", [&] { TestPlainDecoders(dev); }},
         {"TestDictDecoder_int32", [&] { TestDictDecoder<int32_t>(dev); }},
         {"TestDictDecoder_int64", [&] { TestDictDecoder<int64_t>(dev); }},
         {"TestDecodePackedArray", [&] { TestDecodePackedArray(dev); }},

@@ -18,7 +18,7 @@ INT32_OUT_OF_RANGE, VARINT_OVERFLOW, INVALID_BLOCK_SIZE, INVALID_MINIBLOCK_COUNT
 INVALID_MINIBLOCK_WIDTH, DICT_INVALID_WIDTH, DICT_INVALID_INDEX, NOT_INITIALIZED = 10, 11, 12, 13
 INVALID_STREAM, PAGE_VALUES_FAILED = 14, 15
 
-VALUES_DICT, VALUES_DELTA32, VALUES_DELTA64 = 1, 2, 3
+VALUES_DICT, VALUES_DELTA32, VALUES_DELTA64, VALUES_PLAIN, VALUES_BOOL_PLAIN = 1, 2, 3, 4, 5
 
 
 def build():
@@ -168,6 +168,26 @@ def delta_decode64(src, n):
     return _delta(lib().pqo_delta_decode64, np.int64, src, n)
 
 
+def plain_decode(src, n, dtype):
+    """-> dict(status, values[:n_decoded], n_decoded, consumed)"""
+    s = _u8(src)
+    dt = np.dtype(dtype)
+    out = np.zeros(max(n, 1), dtype=dt)
+    nd, cons = C.c_uint32(0), C.c_uint64(0)
+    st = lib().pqo_plain_decode(_ptr(s), C.c_size_t(s.size), C.c_uint32(dt.itemsize), C.c_uint32(n), _ptr(out),
+                                C.byref(nd), C.byref(cons))
+    return dict(status=st, values=out[:nd.value].copy(), n_decoded=nd.value, consumed=cons.value)
+
+
+def bool_plain_decode(src, n):
+    s = _u8(src)
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    nd, cons = C.c_uint32(0), C.c_uint64(0)
+    st = lib().pqo_bool_plain_decode(_ptr(s), C.c_size_t(s.size), C.c_uint32(n), _ptr(out), C.byref(nd),
+                                     C.byref(cons))
+    return dict(status=st, values=out[:nd.value].copy(), n_decoded=nd.value, consumed=cons.value)
+
+
 def hybrid_encode(values, w):
     v = np.ascontiguousarray(values, dtype=np.int32)
     cap = v.size * 5 + v.size // 8 + 64
@@ -218,6 +238,11 @@ def page_read(src, version, num_values, max_rep, max_def, value_kind, dictionary
         pin.dict_len = d.size
         pin.elem_size = d.dtype.itemsize
         vdt = d.dtype
+    elif value_kind == VALUES_PLAIN:
+        vdt = np.dtype(value_dtype)
+        pin.elem_size = vdt.itemsize
+    elif value_kind == VALUES_BOOL_PLAIN:
+        vdt = np.dtype(np.int32)
     else:
         vdt = np.dtype(np.int32 if value_kind == VALUES_DELTA32 else np.int64)
     if value_dtype is not None:

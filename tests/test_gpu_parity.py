@@ -452,7 +452,7 @@ def test_delta_fuzz_headers_and_bodies(ctx, bits):
 # ---------------------------------------------------------------------------
 # a12: whole data pages
 
-def _make_page(rng, version, n, max_rep, max_def, value_kind, dictionary=None, p_max=0.8):
+def _make_page(rng, version, n, max_rep, max_def, value_kind, dictionary=None, p_max=0.8, plain_dtype=None):
     rep = rng.integers(0, max_rep + 1, size=n) if max_rep else np.zeros(n, np.int64)
     deff = np.where(rng.random(n) < p_max, max_def, rng.integers(0, max_def + 1, size=n)) if max_def else np.zeros(n, np.int64)
     not_null = int((deff == max_def).sum()) if max_rep else (n if max_def == 0 else 0)
@@ -461,6 +461,10 @@ def _make_page(rng, version, n, max_rep, max_def, value_kind, dictionary=None, p
     if value_kind == K.KIND_DICT:
         keys = rng.integers(0, dictionary.size, size=not_null)
         vs = synth.dict_page(keys, dict_len=dictionary.size)
+    elif value_kind == K.KIND_PLAIN:
+        vs = rng.integers(0, 256, size=not_null * np.dtype(plain_dtype).itemsize, dtype=np.uint8)
+    elif value_kind == K.KIND_BOOL_PLAIN:
+        vs = rng.integers(0, 256, size=(not_null + 7) // 8, dtype=np.uint8)
     else:
         bits = 32 if value_kind == K.KIND_DELTA32 else 64
         v = np.cumsum(rng.integers(-9, 5000, size=not_null)).astype(np.int32 if bits == 32 else np.int64)
@@ -478,9 +482,11 @@ def _make_page(rng, version, n, max_rep, max_def, value_kind, dictionary=None, p
 
 
 def _check_page(c):
-    ok = {K.KIND_DICT: O.VALUES_DICT, K.KIND_DELTA32: O.VALUES_DELTA32, K.KIND_DELTA64: O.VALUES_DELTA64}
+    ok = {K.KIND_DICT: O.VALUES_DICT, K.KIND_DELTA32: O.VALUES_DELTA32, K.KIND_DELTA64: O.VALUES_DELTA64,
+          K.KIND_PLAIN: O.VALUES_PLAIN, K.KIND_BOOL_PLAIN: O.VALUES_BOOL_PLAIN}
     want = O.page_read(c.src, 1 if c.kind == K.KIND_PAGE_V1 else 2, c.n, c.max_rep, c.max_def,
-                       ok[c.value_kind], dictionary=c.dictionary, rep_len=c.rep_len, def_len=c.def_len)
+                       ok[c.value_kind], dictionary=c.dictionary, rep_len=c.rep_len, def_len=c.def_len,
+                       value_dtype=c.plain_dtype)
     r = c.result
     assert r["status"] == want["status"], (r, want)
     assert r["stage"] == want["stage"], (r, want)
@@ -517,6 +523,62 @@ def test_data_pages_vs_oracle(ctx):
                                               value_kind=vk, dictionary=dic, rep_len=0, def_len=dl))
     run_cases(ctx, cases, seed=9)
     for c in cases:
+        _check_page(c)
+
+
+def test_plain_and_boolean_vs_oracle(ctx, golden_dir):
+    """PLAIN fixed-width values and BOOLEAN PLAIN bits, as streams and as the values of data pages."""
+    rng = _rng(70)
+    cases = []
+    for v in _load(golden_dir, "plain.json")["vectors"]:          # the reference's decoder vectors
+        c = Case(K.KIND_PLAIN, np.array(v["data"], dtype=np.uint8), v["n"], plain_dtype=v["dtype"])
+        c.golden = v
+        cases.append(c)
+    for dt in (np.int32, np.int64, np.float32, np.float64):
+        es = np.dtype(dt).itemsize
+        for n in (0, 1, 7, 8, 9, 511, 512, 513, 20000, 100003):
+            src = rng.integers(0, 256, size=n * es, dtype=np.uint8)
+            cases.append(Case(K.KIND_PLAIN, src, n, plain_dtype=dt))
+            cases.append(Case(K.KIND_PLAIN, src, n + 3, plain_dtype=dt))                    # io.EOF
+            if n:
+                cases.append(Case(K.KIND_PLAIN, src[:-1].copy(), n, plain_dtype=dt))        # unexpected EOF
+    for n in (0, 1, 7, 8, 9, 63, 64, 65, 4096, 4097, 20000, 100003):
+        src = rng.integers(0, 256, size=(n + 7) // 8, dtype=np.uint8)
+        cases.append(Case(K.KIND_BOOL_PLAIN, src, n))
+        cases.append(Case(K.KIND_BOOL_PLAIN, src, n + 20))                                  # io.EOF at a group
+        cases.append(Case(K.KIND_BOOL_PLAIN, src[: src.size // 2].copy(), n))
+    run_cases(ctx, cases, seed=11)
+    for c in cases:
+        if c.kind == K.KIND_PLAIN:
+            want = O.plain_decode(c.src, c.n, c.plain_dtype)
+        else:
+            want = O.bool_plain_decode(c.src, c.n)
+        r = c.result
+        assert r["status"] == want["status"], (c.kind, c.n, r, want["status"])
+        assert r["n_decoded"] == want["n_decoded"]
+        assert r["consumed"] == want["consumed"]
+        nd = want["n_decoded"]
+        assert np.array_equal(c.values[:nd].view(np.uint8), want["values"].view(np.uint8))
+        assert guard_ok(c.guard)
+        if hasattr(c, "golden"):
+            assert c.values[:nd].tolist() == c.golden["values"] and nd == c.golden["count"]
+    # as page values
+    pages = []
+    for version in (1, 2):
+        kind = K.KIND_PAGE_V1 if version == 1 else K.KIND_PAGE_V2
+        for n in (0, 1, 9, 1000, 20000):
+            for max_rep, max_def in ((1, 3), (0, 0), (2, 2)):
+                for vk, dt in ((K.KIND_PLAIN, np.int32), (K.KIND_PLAIN, np.float64), (K.KIND_BOOL_PLAIN, None)):
+                    src, rl, dl = _make_page(rng, version, n, max_rep, max_def, vk, plain_dtype=dt)
+                    kw = dict(max_rep=max_rep, max_def=max_def, value_kind=vk, rep_len=rl, def_len=dl)
+                    if dt is not None:
+                        kw["plain_dtype"] = dt
+                    pages.append(Case(kind, src, n, **kw))
+                    if n == 1000:
+                        for cut in (src.size // 2, src.size - 1):
+                            pages.append(Case(kind, src[:cut].copy(), n, **kw))
+    run_cases(ctx, pages, seed=12)
+    for c in pages:
         _check_page(c)
 
 

@@ -125,3 +125,30 @@ def test_unpack_closed_form_random(bits):
         packed = (O.pack8_32(np.array(want, np.uint32).astype(np.int32), w) if bits == 32
                   else O.pack8_64(np.array(want, np.uint64).astype(np.int64), w))
         assert packed.tolist() == data.tolist(), w
+
+
+def test_plain_decoder_vectors(golden_dir):
+    """types/float_test.go:120-171, types/double_test.go:120-171: three values, and two values + io.EOF."""
+    import json
+    import os
+    vs = json.load(open(os.path.join(golden_dir, "plain.json")))["vectors"]
+    assert len(vs) == 4
+    for v in vs:
+        r = O.plain_decode(np.array(v["data"], dtype=np.uint8), v["n"], v["dtype"])
+        assert r["status"] == (O.OK if v["status"] == "ok" else O.EOF)
+        assert r["n_decoded"] == v["count"]
+        assert r["values"].tolist() == v["values"]
+
+
+def test_plain_and_bool_oracle_edges():
+    # a partial last value is io.ErrUnexpectedEOF (binary.Read = io.ReadFull)
+    r = O.plain_decode(np.arange(11, dtype=np.uint8), 3, np.int32)
+    assert r["status"] == O.UNEXPECTED_EOF and r["n_decoded"] == 2 and r["consumed"] == 11
+    r = O.plain_decode(np.zeros(0, np.uint8), 1, np.int64)
+    assert r["status"] == O.EOF and r["n_decoded"] == 0
+    # booleans: bit j of byte i is value 8 i + j; a missing byte is io.EOF at a multiple of 8
+    r = O.bool_plain_decode(np.array([0b10100101, 0x01], dtype=np.uint8), 12)
+    assert r["status"] == O.OK and r["values"].tolist() == [1, 0, 1, 0, 0, 1, 0, 1, 1, 0, 0, 0]
+    assert r["consumed"] == 2
+    r = O.bool_plain_decode(np.array([0xFF], dtype=np.uint8), 12)
+    assert r["status"] == O.EOF and r["n_decoded"] == 8
