@@ -121,6 +121,11 @@ int pq_bitunpack64(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, size_
 #define PQ_KIND_BOOL_PLAIN 9 /* BooleanPlainDecoder.DecodeValues on a fresh decoder
                               (types/boolean.go:59-104): bit j of byte i is value 8 i + j,
                               written as the int32 0 / 1 that unpackByte yields */
+#define PQ_KIND_BOOL_RLE 10  /* BooleanRLEDecoder.Init + DecodeValues (types/boolean.go:173-196): a u32 LE
+                              length, then a hybrid stream of width 1; one int32 0 / 1 per value.
+                              Alone it is PQ_KIND_HYBRID with bit_width 1 and
+                              PQ_FLAG_LENGTH_PREFIXED; as a value_kind it is the values section of
+                              a BOOLEAN page in RLE encoding */
 
 #define PQ_FLAG_LENGTH_PREFIXED 1u /* HYBRID/LEVELS: InitSize (u32 LE length first) */
 #define PQ_FLAG_LEVELS_CONST 2u    /* LEVELS: ConstDecoder(0) (layout/chunk.go:111-124) */
@@ -143,8 +148,8 @@ typedef struct pq_page_desc {
     uint32_t max_def;     /* pages: max definition level; LEVELS: the stream's max level */
     uint32_t rep_len;     /* PAGE_V2: RepetitionLevelsByteLength */
     uint32_t def_len;     /* PAGE_V2: DefinitionLevelsByteLength */
-    uint32_t value_kind;  /* pages: PQ_KIND_DICT, PQ_KIND_DELTA32, PQ_KIND_DELTA64, PQ_KIND_PLAIN
-                             or PQ_KIND_BOOL_PLAIN */
+    uint32_t value_kind;  /* pages: PQ_KIND_DICT, PQ_KIND_DELTA32, PQ_KIND_DELTA64, PQ_KIND_PLAIN,
+                             PQ_KIND_BOOL_PLAIN or PQ_KIND_BOOL_RLE */
     uint32_t elem_size;   /* DICT: bytes per dictionary entry (4 or 8); PLAIN: bytes per value */
     uint32_t dict_len;    /* DICT: number of dictionary entries */
     uint32_t reserved;

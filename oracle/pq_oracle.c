@@ -819,7 +819,9 @@ void pqo_page_read(const pqo_page_in *in, int32_t *rep, int32_t *def, void *valu
 
     dict_dec_t dict;
     delta_t delta;
+    hybrid_t brle;
     memset(&delta, 0, sizeof delta);
+    hybrid_new(&brle, 1);
     int st = PQO_OK;
 
     /* ---- read(): decoder initialisation ---- */
@@ -856,6 +858,9 @@ void pqo_page_read(const pqo_page_in *in, int32_t *rep, int32_t *def, void *valu
     case PQO_VALUES_DELTA64: st = delta_init(&delta, &r, 1); break;
     case PQO_VALUES_PLAIN:   /* Init only keeps the reader (types/int32.go:50-53) */
     case PQO_VALUES_BOOL_PLAIN: st = PQO_OK; break;
+    case PQO_VALUES_BOOL_RLE: /* NewHybridDecoder(1, false).InitSize(reader), types/boolean.go:177-181 */
+        st = hybrid_init_size(&brle, &r, 0);
+        break;
     default: st = PQO_NOT_INITIALIZED; break;
     }
     if (st != PQO_OK) {
@@ -886,6 +891,13 @@ void pqo_page_read(const pqo_page_in *in, int32_t *rep, int32_t *def, void *valu
             st = pqo_plain_decode(r.p + r.pos, r.len - r.pos, in->elem_size, nn, values, &cnt, NULL);
         } else if (in->value_kind == PQO_VALUES_BOOL_PLAIN) {
             st = pqo_bool_plain_decode(r.p + r.pos, r.len - r.pos, nn, (int32_t *)values, &cnt, NULL);
+        } else if (in->value_kind == PQO_VALUES_BOOL_RLE) {
+            for (; cnt < nn; cnt++) { /* dest[i] = n == 1, types/boolean.go:186-193 */
+                int32_t v;
+                st = hybrid_next(&brle, &v);
+                if (st != PQO_OK) break;
+                ((int32_t *)values)[cnt] = v == 1;
+            }
         } else {
             int is64 = in->value_kind == PQO_VALUES_DELTA64;
             for (; cnt < nn; cnt++) {

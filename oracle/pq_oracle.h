@@ -65,7 +65,8 @@ enum pqo_value_kind {
     PQO_VALUES_DELTA32 = 2, /* types.Int32DeltaBPDecoder */
     PQO_VALUES_DELTA64 = 3, /* types.Int64DeltaBPDecoder */
     PQO_VALUES_PLAIN = 4,   /* Int32/Int64/Float/DoublePlainDecoder, elem_size bytes per value */
-    PQO_VALUES_BOOL_PLAIN = 5 /* BooleanPlainDecoder, one int32 0/1 per value */
+    PQO_VALUES_BOOL_PLAIN = 5, /* BooleanPlainDecoder, one int32 0/1 per value */
+    PQO_VALUES_BOOL_RLE = 6    /* BooleanRLEDecoder (types/boolean.go:173-196), one int32 0/1 per value */
 };
 
 /* ---- fixed-width bit packing (encoding/bitpacking32.go, bitpacking64.go) ---- */

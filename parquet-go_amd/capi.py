@@ -20,7 +20,7 @@ INVALID_STREAM, PAGE_VALUES_FAILED = 14, 15
 ERR_BAD_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_OUT_OF_RANGE = 100, 101, 102, 103
 
 KIND_HYBRID, KIND_DICT, KIND_LEVELS, KIND_DELTA32, KIND_DELTA64, KIND_PAGE_V1, KIND_PAGE_V2 = range(1, 8)
-KIND_PLAIN, KIND_BOOL_PLAIN = 8, 9
+KIND_PLAIN, KIND_BOOL_PLAIN, KIND_BOOL_RLE = 8, 9, 10
 FLAG_LENGTH_PREFIXED, FLAG_LEVELS_CONST, FLAG_NO_INIT = 1, 2, 4
 OPT_DELTA_WAVE_MIN_PAGES = 1
 OPT_HYBRID_WAVE_MIN_PAGES = 2

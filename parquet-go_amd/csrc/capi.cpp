@@ -67,7 +67,8 @@ int group_of(uint32_t kind)
     case PQ_KIND_DICT:
     case PQ_KIND_LEVELS:
     case PQ_KIND_PLAIN:
-    case PQ_KIND_BOOL_PLAIN: return 0;
+    case PQ_KIND_BOOL_PLAIN:
+    case PQ_KIND_BOOL_RLE: return 0;
     case PQ_KIND_DELTA32: return 1;
     case PQ_KIND_DELTA64: return 2;
     case PQ_KIND_PAGE_V1:
@@ -87,7 +88,8 @@ uint32_t value_size(const pq_page_desc &d)
     case PQ_KIND_DELTA32: return 4;
     case PQ_KIND_DELTA64: return 8;
     case PQ_KIND_PLAIN: return d.elem_size;
-    case PQ_KIND_BOOL_PLAIN: return 4;
+    case PQ_KIND_BOOL_PLAIN:
+    case PQ_KIND_BOOL_RLE: return 4;
     default: return 0;
     }
 }
@@ -99,7 +101,8 @@ int validate(const pq_page_desc &d)
     if (d.src_len > 0x7fffffffffffull) return PQ_ERR_BAD_ARGUMENT;
     const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
     if (page && d.value_kind != PQ_KIND_DICT && d.value_kind != PQ_KIND_DELTA32 &&
-        d.value_kind != PQ_KIND_DELTA64 && d.value_kind != PQ_KIND_PLAIN && d.value_kind != PQ_KIND_BOOL_PLAIN)
+        d.value_kind != PQ_KIND_DELTA64 && d.value_kind != PQ_KIND_PLAIN && d.value_kind != PQ_KIND_BOOL_PLAIN &&
+        d.value_kind != PQ_KIND_BOOL_RLE)
         return PQ_ERR_BAD_ARGUMENT;
     const bool plain = d.kind == PQ_KIND_PLAIN || (page && d.value_kind == PQ_KIND_PLAIN);
     if (plain && d.elem_size != 4 && d.elem_size != 8) return PQ_ERR_BAD_ARGUMENT;

@@ -50,6 +50,7 @@ __device__ __forceinline__ Section section_init_size(const uint8_t *S, int64_t a
     if (w == 0) return s;
     if (avail < 4) {
         s.init_status = avail <= 0 ? PQ_EOF : PQ_UNEXPECTED_EOF;
+        s.consumed_by_init = avail <= 0 ? 0u : (uint32_t)avail; // io.ReadFull took what there was
         return s;
     }
     const uint32_t size = load_le32(S);
@@ -182,15 +183,17 @@ __global__ __launch_bounds__(kWG) void stream_pages_kernel(const pq_page_desc *_
 
     HybridResult r{PQ_OK, 0, 0, 0};
     uint32_t extra = 0;
-    if (d.kind == PQ_KIND_HYBRID || d.kind == PQ_KIND_LEVELS) {
-        const bool levels = d.kind == PQ_KIND_LEVELS;
-        const uint32_t w = levels ? bits_len16(d.max_def) : d.bit_width;
+    if (d.kind == PQ_KIND_HYBRID || d.kind == PQ_KIND_LEVELS || d.kind == PQ_KIND_BOOL_RLE) {
+        // BOOL_RLE: NewHybridDecoder(1, false).InitSize (types/boolean.go:177-181)
+        const bool levels = d.kind == PQ_KIND_LEVELS, brle = d.kind == PQ_KIND_BOOL_RLE;
+        const uint32_t w = levels ? bits_len16(d.max_def) : brle ? 1u : d.bit_width;
+        const uint32_t flags = brle ? (uint32_t)PQ_FLAG_LENGTH_PREFIXED : d.flags;
         uint32_t *dst = reinterpret_cast<uint32_t *>(levels ? buf.levels + d.def_off : buf.values + d.dst_off);
-        if (levels && (d.flags & PQ_FLAG_LEVELS_CONST)) {
+        if (levels && (flags & PQ_FLAG_LEVELS_CONST)) {
             r = const_levels(dst, n, d.max_def);
         } else {
-            Section sec{S, len, PQ_OK, 0, (d.flags & PQ_FLAG_NO_INIT) != 0};
-            if (d.flags & PQ_FLAG_LENGTH_PREFIXED) sec = section_init_size(S, len, w);
+            Section sec{S, len, PQ_OK, 0, (flags & PQ_FLAG_NO_INIT) != 0};
+            if (flags & PQ_FLAG_LENGTH_PREFIXED) sec = section_init_size(S, len, w);
             if (sec.init_status != PQ_OK) {
                 r.status = sec.init_status;
             } else if (levels) {
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(kWG) void stream_pages_kernel(const pq_page_desc *_
             } else {
                 r = run_section<HY_RAW, uint32_t>(sh, sec, w, n, dst, nullptr, 0, 0);
             }
-            if (d.flags & PQ_FLAG_LENGTH_PREFIXED) {
+            if (flags & PQ_FLAG_LENGTH_PREFIXED) {
                 // the buffered decoder slurped its whole section at InitSize
                 r.consumed = sec.consumed_by_init;
             } else if (levels && !sec.no_reader) {
@@ -461,6 +464,16 @@ __device__ __forceinline__ void data_page_wg(PageShared &sh, uint32_t *ldict, co
                                        reinterpret_cast<const uint32_t *>(ldict), in_lds, d.dict_len, &v_init);
         v_status = vr.status;
         v_count = vr.n_decoded;
+    } else if (d.value_kind == PQ_KIND_BOOL_RLE) {
+        // BooleanRLEDecoder: InitSize at read(), then n x Next (types/boolean.go:177-196)
+        const Section sec = section_init_size(VS, vlen, 1u);
+        v_init = sec.init_status;
+        if (v_init == PQ_OK) {
+            const HybridResult vr = run_section<HY_RAW, uint32_t>(
+                sh.hy, sec, 1u, nvals, reinterpret_cast<uint32_t *>(buf.values + d.dst_off), nullptr, 0, 0);
+            v_status = vr.status;
+            v_count = vr.n_decoded;
+        }
     } else if (d.value_kind == PQ_KIND_PLAIN || d.value_kind == PQ_KIND_BOOL_PLAIN) {
         // Init only keeps the reader (types/int32.go:50-53)
         uint32_t *vdst = reinterpret_cast<uint32_t *>(buf.values + d.dst_off);
@@ -631,15 +644,17 @@ __global__ __launch_bounds__(kWG) void stream_wave_kernel(const pq_page_desc *__
     const uint32_t n = d.n_values;
 
     HybridResult r{PQ_OK, 0, 0, 0};
-    if (d.kind == PQ_KIND_HYBRID || d.kind == PQ_KIND_LEVELS) {
-        const bool levels = d.kind == PQ_KIND_LEVELS;
-        const uint32_t w = levels ? bits_len16(d.max_def) : d.bit_width;
+    if (d.kind == PQ_KIND_HYBRID || d.kind == PQ_KIND_LEVELS || d.kind == PQ_KIND_BOOL_RLE) {
+        // BOOL_RLE: NewHybridDecoder(1, false).InitSize (types/boolean.go:177-181)
+        const bool levels = d.kind == PQ_KIND_LEVELS, brle = d.kind == PQ_KIND_BOOL_RLE;
+        const uint32_t w = levels ? bits_len16(d.max_def) : brle ? 1u : d.bit_width;
+        const uint32_t flags = brle ? (uint32_t)PQ_FLAG_LENGTH_PREFIXED : d.flags;
         uint32_t *dst = reinterpret_cast<uint32_t *>(levels ? buf.levels + d.def_off : buf.values + d.dst_off);
-        if (levels && (d.flags & PQ_FLAG_LEVELS_CONST)) {
+        if (levels && (flags & PQ_FLAG_LEVELS_CONST)) {
             r = const_levels_wave(dst, n, d.max_def, lane);
         } else {
-            Section sec{S, len, PQ_OK, 0, (d.flags & PQ_FLAG_NO_INIT) != 0};
-            if (d.flags & PQ_FLAG_LENGTH_PREFIXED) sec = section_init_size(S, len, w);
+            Section sec{S, len, PQ_OK, 0, (flags & PQ_FLAG_NO_INIT) != 0};
+            if (flags & PQ_FLAG_LENGTH_PREFIXED) sec = section_init_size(S, len, w);
             if (sec.init_status != PQ_OK) {
                 r.status = sec.init_status;
             } else if (levels) {
@@ -648,7 +663,7 @@ __global__ __launch_bounds__(kWG) void stream_wave_kernel(const pq_page_desc *__
             } else {
                 r = run_section_wave<HY_RAW, uint32_t>(L, sec, w, n, dst, nullptr, 0, 0, lane);
             }
-            if (d.flags & PQ_FLAG_LENGTH_PREFIXED)
+            if (flags & PQ_FLAG_LENGTH_PREFIXED)
                 r.consumed = sec.consumed_by_init;
             else if (levels && !sec.no_reader)
                 r.consumed = (uint64_t)len;
@@ -806,6 +821,15 @@ __global__ __launch_bounds__(kWG) void data_wave_kernel(const pq_page_desc *__re
                                             d.dict_len, &v_init, lane);
         v_status = vr.status;
         v_count = vr.n_decoded;
+    } else if (d.value_kind == PQ_KIND_BOOL_RLE) {
+        const Section sec = section_init_size(VS, vlen, 1u);
+        v_init = sec.init_status;
+        if (v_init == PQ_OK) {
+            const HybridResult vr = run_section_wave<HY_RAW, uint32_t>(
+                L, sec, 1u, nvals, reinterpret_cast<uint32_t *>(buf.values + d.dst_off), nullptr, 0, 0, lane);
+            v_status = vr.status;
+            v_count = vr.n_decoded;
+        }
     } else if (d.value_kind == PQ_KIND_PLAIN || d.value_kind == PQ_KIND_BOOL_PLAIN) {
         uint32_t *vdst = reinterpret_cast<uint32_t *>(buf.values + d.dst_off);
         const HybridResult vr = d.value_kind == PQ_KIND_PLAIN

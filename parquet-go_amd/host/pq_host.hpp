@@ -409,8 +409,12 @@ public:
         if (!reader_) return {0, Error(PQ_NOT_INITIALIZED)};
         uint32_t count = 0;
         uint64_t consumed = 0;
-        int st = pq_plain_decode(dev_.ctx(), reader_->cursor(), reader_->Len(), sizeof(T), n, dest, &count, &consumed);
+        // through a staging vector: dest[count..n) stays untouched, as in the reference's loop
+        std::vector<T> tmp(n ? n : 1);
+        int st = pq_plain_decode(dev_.ctx(), reader_->cursor(), reader_->Len(), sizeof(T), n, tmp.data(), &count,
+                                 &consumed);
         check_library(st, "pq_plain_decode");
+        std::memcpy(dest, tmp.data(), (size_t)count * sizeof(T));
         reader_->advance((size_t)consumed);
         return {(int)count, Error(st)};
     }
@@ -450,6 +454,24 @@ public:
 private:
     Device &dev_;
     Reader *reader_ = nullptr;
+};
+
+// ---- types.BooleanRLEDecoder (types/boolean.go:173-196) -----------------------------------------
+class BooleanRLEDecoder {
+public:
+    explicit BooleanRLEDecoder(Device &dev) : decoder_(dev, 1, false) {}
+    Error Init(Reader &r) { return decoder_.InitSize(r); }
+    std::pair<int, Error> DecodeValues(bool *dest, uint32_t n)
+    {
+        std::vector<int32_t> tmp(n ? n : 1);
+        uint32_t count = 0;
+        Error e = decoder_.DecodeBatch(tmp.data(), n, &count);
+        for (uint32_t i = 0; i < count; ++i) dest[i] = tmp[i] == 1;
+        return {(int)count, e};
+    }
+
+private:
+    HybridDecoder decoder_;
 };
 
 // ---- layout.decodePackedArray (layout/helpers.go:68-90) ------------------------------------
@@ -493,7 +515,7 @@ inline PackedLevels decodePackedArray(LevelDecoder d, int count)
 struct ColumnSpec {
     uint16_t maxR = 0, maxD = 0;
     uint32_t valueKind = PQ_KIND_DICT;  // PQ_KIND_DICT (RLE_DICTIONARY), PQ_KIND_DELTA32, PQ_KIND_DELTA64,
-                                        // PQ_KIND_PLAIN, PQ_KIND_BOOL_PLAIN (elemSize 4: int32 0 / 1)
+                                        // PQ_KIND_PLAIN, PQ_KIND_BOOL_PLAIN, PQ_KIND_BOOL_RLE (int32 0 / 1)
     uint32_t elemSize = 4;              // bytes per value
     const void *dict = nullptr;         // PLAIN-decoded dictionary page (DICT only)
     uint32_t dictLen = 0;

@@ -32,7 +32,8 @@ class Case:
             return self.dictionary.dtype.itemsize
         if k == capi.KIND_PLAIN:
             return self.plain_dtype.itemsize
-        return {capi.KIND_HYBRID: 4, capi.KIND_DELTA32: 4, capi.KIND_DELTA64: 8, capi.KIND_BOOL_PLAIN: 4}.get(k, 0)
+        return {capi.KIND_HYBRID: 4, capi.KIND_DELTA32: 4, capi.KIND_DELTA64: 8, capi.KIND_BOOL_PLAIN: 4,
+                capi.KIND_BOOL_RLE: 4}.get(k, 0)
 
     def value_dtype(self):
         k = self.value_kind if self.kind in (capi.KIND_PAGE_V1, capi.KIND_PAGE_V2) else self.kind
@@ -41,7 +42,7 @@ class Case:
         if k == capi.KIND_PLAIN:
             return self.plain_dtype
         return {capi.KIND_HYBRID: np.int32, capi.KIND_DELTA32: np.int32, capi.KIND_DELTA64: np.int64,
-                capi.KIND_BOOL_PLAIN: np.int32}.get(k, np.uint8)
+                capi.KIND_BOOL_PLAIN: np.int32, capi.KIND_BOOL_RLE: np.int32}.get(k, np.uint8)
 
 
 def run_cases(ctx, cases, seed=0):

@@ -359,6 +359,28 @@ static void TestPlainDecoders(Device &dev)
         CHECK(res.second.is(PQ_EOF));
         CHECK_EQ(res.first, 16);
     }
+    {  // BooleanRLEDecoder: u32 length, hybrid width 1; checked against the oracle
+        std::vector<int32_t> bits(5000);
+        for (size_t i = 0; i < bits.size(); ++i) bits[i] = (i / 37) & 1 ? 1 : (int32_t)(rnd() & 1);
+        std::vector<uint8_t> enc(bits.size() + 64);
+        size_t len = 0;
+        CHECK_EQ(pqo_hybrid_encode(bits.data(), bits.size(), 1, enc.data(), enc.size(), &len), 0);
+        std::vector<uint8_t> s = {(uint8_t)len, (uint8_t)(len >> 8), (uint8_t)(len >> 16), (uint8_t)(len >> 24)};
+        s.insert(s.end(), enc.begin(), enc.begin() + len);
+        Reader r(s);
+        BooleanRLEDecoder d(dev);
+        CHECK(!d.Init(r));
+        std::vector<char> got(bits.size() + 100);
+        auto res = d.DecodeValues(reinterpret_cast<bool *>(got.data()), (uint32_t)bits.size());
+        CHECK(!res.second);
+        CHECK_EQ(res.first, bits.size());
+        bool same = true;
+        for (size_t i = 0; i < bits.size(); ++i) same = same && (got[i] != 0) == (bits[i] == 1);
+        CHECK(same);
+        std::vector<uint8_t> shortS(s.begin(), s.begin() + 3);
+        Reader r2(shortS);
+        CHECK(d.Init(r2).is(PQ_UNEXPECTED_EOF));
+    }
 }
 
 // ---- types.DictDecoder (no reference test; checked against the oracle) ---------------------------

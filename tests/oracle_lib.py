@@ -18,7 +18,7 @@ INT32_OUT_OF_RANGE, VARINT_OVERFLOW, INVALID_BLOCK_SIZE, INVALID_MINIBLOCK_COUNT
 INVALID_MINIBLOCK_WIDTH, DICT_INVALID_WIDTH, DICT_INVALID_INDEX, NOT_INITIALIZED = 10, 11, 12, 13
 INVALID_STREAM, PAGE_VALUES_FAILED = 14, 15
 
-VALUES_DICT, VALUES_DELTA32, VALUES_DELTA64, VALUES_PLAIN, VALUES_BOOL_PLAIN = 1, 2, 3, 4, 5
+VALUES_DICT, VALUES_DELTA32, VALUES_DELTA64, VALUES_PLAIN, VALUES_BOOL_PLAIN, VALUES_BOOL_RLE = 1, 2, 3, 4, 5, 6
 
 
 def build():
@@ -241,7 +241,7 @@ def page_read(src, version, num_values, max_rep, max_def, value_kind, dictionary
     elif value_kind == VALUES_PLAIN:
         vdt = np.dtype(value_dtype)
         pin.elem_size = vdt.itemsize
-    elif value_kind == VALUES_BOOL_PLAIN:
+    elif value_kind in (VALUES_BOOL_PLAIN, VALUES_BOOL_RLE):
         vdt = np.dtype(np.int32)
     else:
         vdt = np.dtype(np.int32 if value_kind == VALUES_DELTA32 else np.int64)

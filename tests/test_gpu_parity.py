@@ -465,6 +465,8 @@ def _make_page(rng, version, n, max_rep, max_def, value_kind, dictionary=None, p
         vs = rng.integers(0, 256, size=not_null * np.dtype(plain_dtype).itemsize, dtype=np.uint8)
     elif value_kind == K.KIND_BOOL_PLAIN:
         vs = rng.integers(0, 256, size=(not_null + 7) // 8, dtype=np.uint8)
+    elif value_kind == K.KIND_BOOL_RLE:
+        vs = synth.length_prefixed(synth.hybrid_encode(_runny(rng, not_null, 1, 40), 1))
     else:
         bits = 32 if value_kind == K.KIND_DELTA32 else 64
         v = np.cumsum(rng.integers(-9, 5000, size=not_null)).astype(np.int32 if bits == 32 else np.int64)
@@ -483,7 +485,8 @@ def _make_page(rng, version, n, max_rep, max_def, value_kind, dictionary=None, p
 
 def _check_page(c):
     ok = {K.KIND_DICT: O.VALUES_DICT, K.KIND_DELTA32: O.VALUES_DELTA32, K.KIND_DELTA64: O.VALUES_DELTA64,
-          K.KIND_PLAIN: O.VALUES_PLAIN, K.KIND_BOOL_PLAIN: O.VALUES_BOOL_PLAIN}
+          K.KIND_PLAIN: O.VALUES_PLAIN, K.KIND_BOOL_PLAIN: O.VALUES_BOOL_PLAIN,
+          K.KIND_BOOL_RLE: O.VALUES_BOOL_RLE}
     want = O.page_read(c.src, 1 if c.kind == K.KIND_PAGE_V1 else 2, c.n, c.max_rep, c.max_def,
                        ok[c.value_kind], dictionary=c.dictionary, rep_len=c.rep_len, def_len=c.def_len,
                        value_dtype=c.plain_dtype)
@@ -547,10 +550,20 @@ def test_plain_and_boolean_vs_oracle(ctx, golden_dir):
         cases.append(Case(K.KIND_BOOL_PLAIN, src, n))
         cases.append(Case(K.KIND_BOOL_PLAIN, src, n + 20))                                  # io.EOF at a group
         cases.append(Case(K.KIND_BOOL_PLAIN, src[: src.size // 2].copy(), n))
+    for n in (0, 1, 9, 4097, 100003):                      # BooleanRLEDecoder: InitSize, then n x Next
+        bits = _runny(rng, n, 1, 30)
+        src = synth.length_prefixed(synth.hybrid_encode(bits, 1))
+        cases.append(Case(K.KIND_BOOL_RLE, src, n))
+        cases.append(Case(K.KIND_BOOL_RLE, src, n + 50))
+        cases.append(Case(K.KIND_BOOL_RLE, src[: src.size // 2].copy(), n))
+        cases.append(Case(K.KIND_BOOL_RLE, src[:3].copy(), n))
     run_cases(ctx, cases, seed=11)
     for c in cases:
         if c.kind == K.KIND_PLAIN:
             want = O.plain_decode(c.src, c.n, c.plain_dtype)
+        elif c.kind == K.KIND_BOOL_RLE:
+            st, vals, cons = O.hybrid_decode(c.src, 1, c.n, length_prefixed=True)
+            want = {"status": st, "n_decoded": vals.size, "consumed": cons, "values": vals}
         else:
             want = O.bool_plain_decode(c.src, c.n)
         r = c.result
@@ -568,14 +581,15 @@ def test_plain_and_boolean_vs_oracle(ctx, golden_dir):
         kind = K.KIND_PAGE_V1 if version == 1 else K.KIND_PAGE_V2
         for n in (0, 1, 9, 1000, 20000):
             for max_rep, max_def in ((1, 3), (0, 0), (2, 2)):
-                for vk, dt in ((K.KIND_PLAIN, np.int32), (K.KIND_PLAIN, np.float64), (K.KIND_BOOL_PLAIN, None)):
+                for vk, dt in ((K.KIND_PLAIN, np.int32), (K.KIND_PLAIN, np.float64), (K.KIND_BOOL_PLAIN, None),
+                               (K.KIND_BOOL_RLE, None)):
                     src, rl, dl = _make_page(rng, version, n, max_rep, max_def, vk, plain_dtype=dt)
                     kw = dict(max_rep=max_rep, max_def=max_def, value_kind=vk, rep_len=rl, def_len=dl)
                     if dt is not None:
                         kw["plain_dtype"] = dt
                     pages.append(Case(kind, src, n, **kw))
                     if n == 1000:
-                        for cut in (src.size // 2, src.size - 1):
+                        for cut in (src.size // 2, src.size - 1, src.size - 60):
                             pages.append(Case(kind, src[:cut].copy(), n, **kw))
     run_cases(ctx, pages, seed=12)
     for c in pages:
