@@ -162,7 +162,7 @@ struct HwConst {
 
 // Span parse: all 64 lanes parse a candidate run header at window offsets o .. o + 63 at once;
 // the chain of real headers is then followed from lane 0 with one v_readlane per run.  Only
-// complete, well-formed runs with a one-byte header that lie wholly inside [0, wl) qualify;
+// complete, well-formed runs with a one- or two-byte header that lie wholly inside [0, wl) qualify;
 // the chain stops at the first one that does not.  Of the chain, the leading runs that fit
 // `room` values (and the piece table) are appended to the tile under construction: each of
 // their lanes writes its own piece record and start mark.  Returns the number of runs taken.
@@ -175,6 +175,7 @@ struct HwNext {
     uint32_t kind;    // 0: unknown (parse it); 1: RLE; 2: bit-packed
     uint32_t count;   // repeats | groups
     uint32_t value;   // RLE value
+    uint32_t hdr;     // bytes of its header (1 or 2)
 };
 
 __device__ __forceinline__ uint32_t hw_span(HybridWaveLds &L, uint32_t o, uint32_t wl, const HwConst &hc, uint32_t room,
@@ -185,13 +186,15 @@ __device__ __forceinline__ uint32_t hw_span(HybridWaveLds &L, uint32_t o, uint32
     const uint32_t d0 = L.window[i], d1 = L.window[i + 1], d2 = L.window[i + 2];
     const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh);  // bytes p .. p+3
     const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, sh);  // bytes p+4 .. p+7
-    const uint32_t val = __builtin_amdgcn_alignbit(hi, lo, 8u) & hc.vbmask;
-    const uint32_t b0 = lo & 0xffu;
-    const uint32_t cnt = b0 >> 1;
-    const bool isbp = (b0 & 1u) != 0u;
-    const uint32_t nbytes = isbp ? 1u + __umul24(cnt, hc.w) : 1u + hc.vb;
+    const bool two = (lo & 0x80u) != 0u;  // a second header byte follows
+    const uint32_t hdr = two ? 2u : 1u;
+    const uint32_t val = __builtin_amdgcn_alignbit(hi, lo, 8u * hdr) & hc.vbmask;
+    const uint32_t h = two ? (lo & 0x7fu) | ((lo >> 1) & 0x3f80u) : lo & 0xffu;  // the ULEB128 header
+    const uint32_t cnt = h >> 1;
+    const bool isbp = (h & 1u) != 0u;
+    const uint32_t nbytes = hdr + (isbp ? __umul24(cnt, hc.w) : hc.vb);
     const uint32_t nvals = isbp ? cnt * 8u : cnt;
-    const bool ok = b0 < 0x80u && cnt != 0u && p + nbytes <= wl && (isbp || (val & ~hc.wmask) == 0u);
+    const bool ok = (lo & 0x8080u) != 0x8080u && cnt != 0u && p + nbytes <= wl && (isbp || (val & ~hc.wmask) == 0u);
     const uint32_t nextlane = (uint32_t)lane + nbytes;
     const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
     nx.o = o;
@@ -199,6 +202,7 @@ __device__ __forceinline__ uint32_t hw_span(HybridWaveLds &L, uint32_t o, uint32
     nx.kind = 0;
     nx.count = 0;
     nx.value = 0;
+    nx.hdr = 1;
 
     // follow the chain from lane 0: chain = lanes that hold real headers, cur = where it leaves
     // the span (>= 64) or stops at a header that is not simple.  Hand-scheduled: five scalar
@@ -233,17 +237,18 @@ __device__ __forceinline__ uint32_t hw_span(HybridWaveLds &L, uint32_t o, uint32
     const uint64_t untaken = chain & ~tmask;
     if (untaken != 0ull) {
         const uint32_t u = (uint32_t)__builtin_ctzll(untaken);
-        const uint32_t bu = (uint32_t)__builtin_amdgcn_readlane((int)b0, (int)u);
+        const uint32_t hu = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)u);
         nx.o = o + u;
-        nx.kind = (bu & 1u) != 0u ? 2u : 1u;
-        nx.count = bu >> 1;
+        nx.kind = (hu & 1u) != 0u ? 2u : 1u;
+        nx.count = hu >> 1;
         nx.value = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)u);
+        nx.hdr = (uint32_t)__builtin_amdgcn_readlane((int)hdr, (int)u);
     } else {
         nx.o = o + cur;
     }
     if (take) {
         const uint32_t start = fill + incl - nvals;
-        L.pieces[np + rank] = make_uint2(isbp ? 0u : 0xffffffffu, isbp ? (p + 1u) * 8u - __umul24(start, hc.w) : val);
+        L.pieces[np + rank] = make_uint2(isbp ? 0u : 0xffffffffu, isbp ? (p + hdr) * 8u - __umul24(start, hc.w) : val);
         reinterpret_cast<uint8_t *>(L.marks)[phase + start] = 1;
     }
     return (uint32_t)__builtin_popcountll(tmask);
@@ -602,9 +607,10 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
                     // span parse, 64 candidate positions at a time
                     const uint32_t b0 = (uni(L.window[st.o >> 2]) >> ((st.o & 3u) * 8u)) & 0xffu;
                     const uint32_t room = want - fill;
-                    if (b0 < 0x80u && st.o < wl) {
-                        if ((b0 & 1u) != 0u && b0 >= 65u) {
-                            // a bit-packed run of 32 groups and more: no span parse
+                    if (st.o < wl) {
+                        if (b0 < 0x80u && (b0 & 1u) != 0u && b0 >= 65u) {
+                            // a bit-packed run of 32 groups and more: no span parse, and left to
+                            // the bulk path when the tile is half full already
                             if (8u * (b0 >> 1) > room && 2u * fill >= cap) break;
                             st.pend = 2;
                             st.pcount = b0 >> 1;
@@ -621,7 +627,7 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
                                 st.pend = nx.kind;
                                 st.pcount = nx.count;
                                 st.pvalue = nx.value;
-                                st.o = nx.o + 1u + (nx.kind == 1u ? hc.vb : 0u);
+                                st.o = nx.o + nx.hdr + (nx.kind == 1u ? hc.vb : 0u);
                             } else if (taken != 0u) {
                                 continue;
                             }

@@ -533,9 +533,12 @@ __global__ __launch_bounds__(kWG) void data_pages_kernel(const pq_page_desc *__r
 }
 
 // ---------------------------------------------------------------------------
-// One WAVE per descriptor: 4 descriptors per workgroup, no barrier after the optional
+// One WAVE per descriptor: kHwWaves descriptors per workgroup, no barrier after the optional
 // dictionary load.  dict_lds_bytes != 0 promises that every dictionary user of the launch
 // reads the same dictionary, dict_lds_bytes long at buf.dict + dict_lds_off.
+
+constexpr int kHwWG = 512;               // threads per workgroup of the hybrid wave kernels
+constexpr int kHwWaves = kHwWG / kWave;   // descriptors per workgroup
 
 struct WaveDict {
     const uint8_t *g;  // the page's dictionary in global memory
@@ -548,7 +551,7 @@ __device__ __forceinline__ const uint32_t *load_wave_dict(uint8_t *smem_after, P
     if (dict_lds_bytes == 0) return nullptr;
     uint32_t *ldict = reinterpret_cast<uint32_t *>(smem_after);
     const uint32_t *g = reinterpret_cast<const uint32_t *>(buf.dict + dict_lds_off);
-    for (uint32_t i = threadIdx.x; i < dict_lds_bytes / 4u; i += kWG) ldict[i] = g[i];
+    for (uint32_t i = threadIdx.x; i < dict_lds_bytes / 4u; i += kHwWG) ldict[i] = g[i];
     __syncthreads();
     return ldict;
 }
@@ -624,17 +627,17 @@ __device__ __forceinline__ HybridResult bool_values_wave(HybridWaveLds &L, const
     return r;
 }
 
-__global__ __launch_bounds__(kWG) void stream_wave_kernel(const pq_page_desc *__restrict__ descs,
+__global__ __launch_bounds__(kHwWG) void stream_wave_kernel(const pq_page_desc *__restrict__ descs,
                                                           const uint32_t *__restrict__ ids, uint32_t count,
                                                           PageBuffers buf, pq_page_result *__restrict__ results,
                                                           uint32_t dict_lds_bytes, uint64_t dict_lds_off)
 {
     HybridWaveLds *LW = reinterpret_cast<HybridWaveLds *>(pq_smem);
-    const uint32_t *ldict = load_wave_dict(pq_smem + align16((uint32_t)sizeof(HybridWaveLds) * (kWG / kWave)), buf,
+    const uint32_t *ldict = load_wave_dict(pq_smem + align16((uint32_t)sizeof(HybridWaveLds) * (kHwWaves)), buf,
                                            dict_lds_bytes, dict_lds_off);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t slot = blockIdx.x * (kWG / kWave) + (uint32_t)wave;
+    const uint32_t slot = blockIdx.x * (kHwWaves) + (uint32_t)wave;
     if (slot >= count) return;
     HybridWaveLds &L = LW[wave];
     const uint32_t page = ids[slot];
@@ -697,18 +700,18 @@ __global__ __launch_bounds__(kWG) void stream_wave_kernel(const pq_page_desc *__
 }
 
 // A whole V1 / V2 data page by one wave: same order and error precedence as data_page_wg.
-__global__ __launch_bounds__(kWG) void data_wave_kernel(const pq_page_desc *__restrict__ descs,
+__global__ __launch_bounds__(kHwWG) void data_wave_kernel(const pq_page_desc *__restrict__ descs,
                                                         const uint32_t *__restrict__ ids, uint32_t count,
                                                         PageBuffers buf, pq_page_result *__restrict__ results,
                                                         uint32_t dict_lds_bytes, uint64_t dict_lds_off,
                                                         uint32_t *flag, uint32_t epoch)
 {
     HybridWaveLds *LW = reinterpret_cast<HybridWaveLds *>(pq_smem);
-    const uint32_t *ldict = load_wave_dict(pq_smem + align16((uint32_t)sizeof(HybridWaveLds) * (kWG / kWave)), buf,
+    const uint32_t *ldict = load_wave_dict(pq_smem + align16((uint32_t)sizeof(HybridWaveLds) * (kHwWaves)), buf,
                                            dict_lds_bytes, dict_lds_off);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t slot = blockIdx.x * (kWG / kWave) + (uint32_t)wave;
+    const uint32_t slot = blockIdx.x * (kHwWaves) + (uint32_t)wave;
     if (slot >= count) return;
     HybridWaveLds &L = LW[wave];
     const uint32_t page = ids[slot];
@@ -911,7 +914,16 @@ __global__ __launch_bounds__(kWave) void delta_serial_kernel(const pq_page_desc 
 
 static size_t wave_lds_bytes(uint32_t dict_lds_bytes)
 {
-    return align16((uint32_t)sizeof(HybridWaveLds) * (kWG / kWave)) + dict_lds_bytes;
+    return align16((uint32_t)sizeof(HybridWaveLds) * kHwWaves) + dict_lds_bytes;
+}
+
+// More than 64 KiB of dynamic LDS (a large shared dictionary) has to be asked for.
+template <typename K>
+static hipError_t allow_lds(K kernel, size_t bytes)
+{
+    if (bytes <= 65536) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes);
 }
 
 hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
@@ -920,8 +932,10 @@ hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const
 {
     if (count == 0) return hipSuccess;
     if (count >= wl.min_pages) {
-        const uint32_t grid = (count + kWG / kWave - 1) / (kWG / kWave);
-        hipLaunchKernelGGL(stream_wave_kernel, dim3(grid), dim3(kWG), wave_lds_bytes(wl.dict_lds_bytes), s, d_descs,
+        const uint32_t grid = (count + kHwWaves - 1) / kHwWaves;
+        const hipError_t e = allow_lds(stream_wave_kernel, wave_lds_bytes(wl.dict_lds_bytes));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(stream_wave_kernel, dim3(grid), dim3(kHwWG), wave_lds_bytes(wl.dict_lds_bytes), s, d_descs,
                            d_ids, count, buf, d_results, wl.dict_lds_bytes, wl.dict_lds_off);
         return hipGetLastError();
     }
@@ -986,8 +1000,10 @@ hipError_t launch_data_pages(hipStream_t s, const pq_page_desc *d_descs, const u
     if (count == 0) return hipSuccess;
     const size_t shmem = align16(sizeof(PageShared)) + dict_lds_bytes;
     if (count >= wl.min_pages) {
-        const uint32_t grid = (count + kWG / kWave - 1) / (kWG / kWave);
-        hipLaunchKernelGGL(data_wave_kernel, dim3(grid), dim3(kWG), wave_lds_bytes(wl.dict_lds_bytes), s, d_descs,
+        const uint32_t grid = (count + kHwWaves - 1) / kHwWaves;
+        const hipError_t ea = allow_lds(data_wave_kernel, wave_lds_bytes(wl.dict_lds_bytes));
+        if (ea != hipSuccess) return ea;
+        hipLaunchKernelGGL(data_wave_kernel, dim3(grid), dim3(kHwWG), wave_lds_bytes(wl.dict_lds_bytes), s, d_descs,
                            d_ids, count, buf, d_results, wl.dict_lds_bytes, wl.dict_lds_off, d_flag, epoch);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

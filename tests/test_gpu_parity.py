@@ -215,7 +215,19 @@ def _random_run_stream(rng, w, target_bytes):
     out = bytearray()
     vb = (w + 7) // 8
     while len(out) < target_bytes:
-        kind = rng.integers(0, 4)
+        kind = rng.integers(0, 24) % 6 if len(out) > 200 else rng.integers(0, 4)
+        if kind >= 4:
+            # a header in more bytes than it needs (binary.ReadUvarint takes it), or a
+            # three-byte one (an RLE run of 8192 repeats and more)
+            bp = bool(rng.integers(0, 2)) and kind == 4
+            cnt = int(rng.integers(1, 40)) if kind == 4 else int(rng.integers(8192, 20000))
+            h = (cnt << 1) | (1 if bp else 0)
+            out += bytes([0x80 | (h & 0x7F), (h >> 7) & 0x7F] if kind == 4 else synth.uleb128(h))
+            if bp:
+                out += rng.integers(0, 256, size=cnt * w, dtype=np.uint8).tobytes()
+            else:
+                out += int(rng.integers(0, 1 << w)).to_bytes(8, "little")[:vb]
+            continue
         if kind == 0:                                   # short RLE
             cnt, bp = int(rng.integers(1, 20)), False
         elif kind == 1:                                 # long RLE (two-byte header from 64 on)

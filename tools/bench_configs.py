@@ -7,6 +7,7 @@ device-resident, HIP-event timed.  Prints one JSON object per configuration.
   C3  plain bit-unpack sweep (int32 and int64 widths), 256 MiB encoded per width
   C4  nested V1 data pages: rep (w=1) + def (w=2) levels + dictionary values
   C2x INT64 delta at other miniblock widths / INT32 delta
+  P   PLAIN int64 / int32 values, BOOLEAN PLAIN bits, BOOLEAN RLE runs
 """
 import argparse
 import json
@@ -190,6 +191,47 @@ def bench_delta(ctx, stream, pages, n, bits, width):
     plan.close()
 
 
+def bench_plain(ctx, stream, pages, n, kind, es, label):
+    """kind: KIND_PLAIN (es bytes per value), KIND_BOOL_PLAIN or KIND_BOOL_RLE (int32 0 / 1 out)."""
+    rng = np.random.default_rng(6)
+    distinct = min(pages, 64)
+    streams, want = [], []
+    for p in range(distinct):
+        if kind == capi.KIND_PLAIN:
+            s = rng.integers(0, 256, size=n * es, dtype=np.uint8)
+            want.append(s.view(np.int32 if es == 4 else np.int64))
+        elif kind == capi.KIND_BOOL_PLAIN:
+            s = rng.integers(0, 256, size=(n + 7) // 8, dtype=np.uint8)
+            want.append(np.unpackbits(s, bitorder="little")[:n].astype(np.int32))
+        else:
+            bits = runny(rng, n, 2, 24)
+            s = synth.length_prefixed(synth.hybrid_encode(bits, 1)).astype(np.uint8)
+            want.append(bits.astype(np.int32))
+        streams.append(s)
+    while len(streams) < pages:
+        streams.append(streams[len(streams) % distinct])
+        want.append(want[len(want) % distinct])
+    src, offs, lens = pack_pages(streams)
+    oes = es if kind == capi.KIND_PLAIN else 4
+    descs = np.zeros(pages, dtype=capi.DESC_DTYPE)
+    descs["kind"] = kind
+    descs["src_off"], descs["src_len"], descs["n_values"] = offs, lens, n
+    descs["elem_size"] = es
+    descs["dst_off"] = np.arange(pages, dtype=np.uint64) * np.uint64(oes * n)
+    t_src = torch.from_numpy(src).to(DEV)
+    t_out = torch.empty(pages * n * oes, dtype=torch.uint8, device=DEV)
+    plan = ctx.plan(descs)
+    fn = lambda: plan.run(t_src.data_ptr(), src.size, t_out.data_ptr(), pages * n * oes)
+    t = timed(fn, stream)
+    res = plan.results()
+    assert (res["status"] == 0).all() and (res["n_decoded"] == n).all()
+    got = t_out.cpu().numpy().view(np.int64 if oes == 8 else np.int32).reshape(pages, n)
+    for p in (0, pages // 2, pages - 1):
+        assert np.array_equal(got[p], want[p])
+    report(label, int(lens.sum()), pages * n * oes, t, {"pages": pages, "values_per_page": n})
+    plan.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -213,6 +255,11 @@ def main():
         for w in (4, 8, 24, 30):
             bench_delta(ctx, stream, args.pages, 20000, 64, w)
         bench_delta(ctx, stream, args.pages, 20000, 32, 12)
+    if want("plain"):
+        bench_plain(ctx, stream, args.pages, 20000, capi.KIND_PLAIN, 8, "P PLAIN int64")
+        bench_plain(ctx, stream, args.pages, 20000, capi.KIND_PLAIN, 4, "P PLAIN int32")
+        bench_plain(ctx, stream, args.pages, 20000, capi.KIND_BOOL_PLAIN, 4, "P BOOLEAN PLAIN")
+        bench_plain(ctx, stream, args.pages, 20000, capi.KIND_BOOL_RLE, 4, "P BOOLEAN RLE (mean run 24)")
     print("elapsed %.1fs" % (time.time() - t0), file=sys.stderr)
     ctx.close()
 
