@@ -217,6 +217,46 @@ int pq_plain_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t el
 int pq_bool_plain_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n, int32_t *dst,
                          uint32_t *n_decoded, uint64_t *consumed);
 
+/* ---- Level post-processing: what the reference does with decoded levels, value by value ----
+ *
+ * pq_levels_pack*: the bytes of an encoding.PackedArray (encoding/packed-array.go:47-55,118-125,
+ * pack8int32_w of encoding/bitpacking32.go:45-79) holding levels[0..n): AppendSingle x n and, for
+ * n > 0, Flush — ceil(n / 8) groups of bit_width bytes, value i of a group in bits
+ * [i w, (i + 1) w) of it.  This is the container readPageData appends page levels to
+ * (file-reader.go:285-296).  bit_width = bits.Len16(max level), 0..16; levels must be below
+ * 2^bit_width (what decodePackedArray yields).  out_bytes >= ceil(n / 8) * bit_width; d_out 4-byte
+ * aligned.
+ *
+ * pq_column_entries*: ColumnStore.Get (datastore/column.go:127-177, reached from Column.GetData,
+ * schema/column.go:132-162) called until the store is exhausted, over a column whose level arrays
+ * are def[0..n) / rep[0..n).  Entry k is the k-th call:
+ *   validity bit k (LSB-first)  the call returned a value (REPEATED: the array of values collected
+ *                               while the repetition level stays >= max_rep), not nil
+ *   entry_def[k]                the definition level it returned (max_def for a value)
+ *   offsets[k]                  values handed out by GetNext before it; offsets[n_entries] = all
+ * so entry k owns values[offsets[k] .. offsets[k + 1]) of the column's dense value array.  rep is
+ * read only when repeated != 0.  Capacities: offsets n + 1, validity 4 * ceil(n / 32) bytes
+ * (written whole), entry_def n.  n <= 2^31 - 1.
+ * The _dev forms take device pointers (result included) and run asynchronously on the context's
+ * stream; their scratch memory belongs to the context and grows on demand. */
+typedef struct pq_entries_result {
+    int32_t status;     /* PQ_OK */
+    uint32_t n_entries; /* calls that returned without "out of range" */
+    uint32_t n_values;  /* values they consumed */
+    uint32_t reserved;
+} pq_entries_result;
+
+int pq_levels_pack_dev(pq_ctx *ctx, const int32_t *d_levels, uint64_t n, int bit_width, void *d_out,
+                       uint64_t out_bytes);
+int pq_levels_pack(pq_ctx *ctx, const int32_t *levels, uint64_t n, int bit_width, uint8_t *out,
+                   uint64_t out_bytes);
+int pq_column_entries_dev(pq_ctx *ctx, const int32_t *d_def, const int32_t *d_rep, uint64_t n,
+                          uint32_t max_def, uint32_t max_rep, int repeated, uint32_t *d_offsets,
+                          void *d_validity, int32_t *d_entry_def, pq_entries_result *d_result);
+int pq_column_entries(pq_ctx *ctx, const int32_t *def, const int32_t *rep, uint64_t n, uint32_t max_def,
+                      uint32_t max_rep, int repeated, uint32_t *offsets, uint8_t *validity,
+                      int32_t *entry_def, pq_entries_result *result);
+
 #ifdef __cplusplus
 }
 #endif

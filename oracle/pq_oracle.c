@@ -540,6 +540,58 @@ int pqo_levels_decode(const uint8_t *src, size_t src_len, uint32_t max_level, in
     return st;
 }
 
+/* The bytes of a PackedArray after AppendSingle x n and, for n > 0, Flush
+ * (packed-array.go:47-55,118-125): ceil(n / 8) groups of w bytes. */
+uint64_t pqo_levels_pack(const int32_t *levels, uint64_t n, int w, uint8_t *out)
+{
+    packed_array_t a;
+    packed_reset(&a, w, out);
+    for (uint64_t i = 0; i < n; i++) packed_append(&a, levels[i]);
+    if (n > 0) packed_flush(&a);
+    return a.data_len;
+}
+
+/* ColumnStore.Get (datastore/column.go:127-177) called until it reports "out of range",
+ * over a column store whose level arrays hold def[0..n) and rep[0..n) (what readPageData
+ * appended, file-reader.go:285-296).  Entry k is the k-th call: validity bit k says it
+ * returned a value (a scalar, or for a REPEATED column the array collected while the
+ * repetition level stays >= maxR), entry_def[k] the definition level it returned,
+ * offsets[k] how many values GetNext had handed out before it; offsets[n_entries] is the
+ * total.  Every position of a value entry takes a value, whatever its own definition
+ * level (column.go:161-176 calls GetNext without looking at it). */
+void pqo_column_entries(const int32_t *def, const int32_t *rep, uint64_t n, int32_t max_def,
+                        int32_t max_rep, int repeated, uint32_t *offsets, uint8_t *validity,
+                        int32_t *entry_def, uint32_t *n_entries, uint32_t *n_values)
+{
+    uint64_t read_pos = 0;
+    uint32_t k = 0, vals = 0;
+    memset(validity, 0, (size_t)((n + 31) / 32 * 4));
+    while (read_pos < n) {
+        int32_t dl = def[read_pos];
+        offsets[k] = vals;
+        if (dl < max_def) { /* a null: advance the levels only (column.go:139-142) */
+            entry_def[k++] = dl;
+            read_pos++;
+            continue;
+        }
+        vals++; /* GetNext, column.go:144 */
+        validity[k >> 3] |= (uint8_t)(1u << (k & 7));
+        entry_def[k++] = max_def;
+        if (!repeated) { /* column.go:150-153 */
+            read_pos++;
+            continue;
+        }
+        for (;;) { /* column.go:161-176 */
+            read_pos++;
+            if (read_pos >= n || rep[read_pos] < max_rep) break;
+            vals++;
+        }
+    }
+    offsets[k] = vals;
+    *n_entries = k;
+    *n_values = vals;
+}
+
 /* ------------------------------------------------------------------------- */
 /* DELTA_BINARY_PACKED: encoding/delta-binary-packed-decoder.go:11-322         */
 

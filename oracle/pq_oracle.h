@@ -151,6 +151,17 @@ typedef struct pqo_page_out {
 void pqo_page_read(const pqo_page_in *in, int32_t *rep, int32_t *def, void *values,
                    pqo_page_out *out);
 
+/* ---- level post-processing ----
+ * pqo_levels_pack: PackedArray bytes (encoding/packed-array.go:47-55,118-125) of n levels at
+ * width w: AppendSingle x n, then Flush when n > 0.  out: ceil(n / 8) * w bytes.  Returns them. */
+uint64_t pqo_levels_pack(const int32_t *levels, uint64_t n, int w, uint8_t *out);
+/* pqo_column_entries: ColumnStore.Get (datastore/column.go:127-177) repeated to the end of the
+ * store.  offsets: n + 1, validity: 4 * ceil(n / 32) bytes (LSB-first), entry_def: n.
+ * rep is only read when repeated != 0. */
+void pqo_column_entries(const int32_t *def, const int32_t *rep, uint64_t n, int32_t max_def,
+                        int32_t max_rep, int repeated, uint32_t *offsets, uint8_t *validity,
+                        int32_t *entry_def, uint32_t *n_entries, uint32_t *n_values);
+
 /* ---- encoders, used only to generate inputs the reference itself would produce
  *      (encoding/hybrid-encoder.go, encoding/delta-binary-packed-encoder.go) ---- */
 int pqo_hybrid_encode(const int32_t *values, size_t n, int w, uint8_t *out, size_t cap,

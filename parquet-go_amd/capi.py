@@ -34,6 +34,7 @@ EXPORTS = [
     "pq_plan_create", "pq_plan_run", "pq_plan_results", "pq_plan_destroy", "pq_decode_pages",
     "pq_hybrid_decode", "pq_dict_decode", "pq_levels_decode", "pq_delta_decode32",
     "pq_delta_decode64", "pq_plain_decode", "pq_bool_plain_decode",
+    "pq_levels_pack_dev", "pq_levels_pack", "pq_column_entries_dev", "pq_column_entries",
 ]
 
 
@@ -50,6 +51,11 @@ class PageResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("stage", C.c_int32), ("detail", C.c_int32),
                 ("n_decoded", C.c_uint32), ("not_null", C.c_uint32), ("n_levels", C.c_uint32),
                 ("consumed", C.c_uint64)]
+
+
+class EntriesResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_entries", C.c_uint32), ("n_values", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 DESC_DTYPE = np.dtype([("kind", "<u4"), ("flags", "<u4"), ("src_off", "<u8"), ("src_len", "<u8"),
@@ -118,6 +124,11 @@ def load():
                                            C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         lib.pq_plain_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32,
                                         C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        for name in ("pq_levels_pack_dev", "pq_levels_pack"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
+        for name in ("pq_column_entries_dev", "pq_column_entries"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                           C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pq_bool_plain_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         _lib = lib
@@ -260,6 +271,44 @@ class Context:
         return results, values, levels
 
     # ---- device-resident entry points (raw device pointers) ----
+    def levels_pack(self, levels, bit_width):
+        """PackedArray bytes of `levels` (AppendSingle x n, Flush): ceil(n / 8) * bit_width bytes."""
+        lv = np.ascontiguousarray(levels, dtype=np.int32)
+        need = (lv.size + 7) // 8 * bit_width
+        out = np.zeros(max(need, 1), dtype=np.uint8)
+        self._check(self._lib.pq_levels_pack(self._h, _ptr(lv), lv.size, int(bit_width), _ptr(out), need), "pack")
+        return out[:need]
+
+    def levels_pack_dev(self, d_levels, n, bit_width, d_out, out_bytes):
+        st = self._lib.pq_levels_pack_dev(self._h, C.c_void_p(d_levels), int(n), int(bit_width), C.c_void_p(d_out),
+                                          int(out_bytes))
+        if st != OK:
+            raise PqError(st, self._lib.pq_last_error(self._h).decode())
+
+    def column_entries(self, def_levels, rep_levels, max_def, max_rep, repeated):
+        """ColumnStore.Get to the end of the store -> dict(n_entries, n_values, offsets, validity, entry_def)."""
+        d = np.ascontiguousarray(def_levels, dtype=np.int32)
+        r = np.ascontiguousarray(rep_levels, dtype=np.int32) if rep_levels is not None else np.zeros(0, np.int32)
+        n = d.size
+        offsets = np.zeros(n + 1, dtype=np.uint32)
+        validity = np.zeros((n + 31) // 32 * 4 + 4, dtype=np.uint8)
+        entry_def = np.zeros(max(n, 1), dtype=np.int32)
+        res = EntriesResult()
+        self._check(self._lib.pq_column_entries(self._h, _ptr(d) if n else None, _ptr(r) if r.size else None, n,
+                                                int(max_def), int(max_rep), int(bool(repeated)), _ptr(offsets),
+                                                _ptr(validity), _ptr(entry_def), C.byref(res)), "entries")
+        ne = res.n_entries
+        return dict(n_entries=ne, n_values=res.n_values, offsets=offsets[:ne + 1].copy(),
+                    validity=validity[:(n + 31) // 32 * 4].copy(), entry_def=entry_def[:ne].copy())
+
+    def column_entries_dev(self, d_def, d_rep, n, max_def, max_rep, repeated, d_offsets, d_validity, d_entry_def,
+                           d_result):
+        st = self._lib.pq_column_entries_dev(self._h, C.c_void_p(d_def), C.c_void_p(d_rep), int(n), int(max_def),
+                                             int(max_rep), int(bool(repeated)), C.c_void_p(d_offsets),
+                                             C.c_void_p(d_validity), C.c_void_p(d_entry_def), C.c_void_p(d_result))
+        if st != OK:
+            raise PqError(st, self._lib.pq_last_error(self._h).decode())
+
     def bitunpack_dev(self, d_src, src_len, w, n_groups, d_dst, bits=32):
         fn = self._lib.pq_bitunpack32_dev if bits == 32 else self._lib.pq_bitunpack64_dev
         st = fn(self._h, C.c_void_p(d_src), int(src_len), int(w), int(n_groups), C.c_void_p(d_dst))

@@ -25,6 +25,9 @@ struct pq_ctx {
     uint32_t hybrid_wave_min_pages = 1;
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_cap[4] = {0, 0, 0, 0};
+    // grow-only scratch of the device-pointer entry points that need one
+    void *work = nullptr;
+    size_t work_cap = 0;
 };
 
 struct pq_plan {
@@ -204,6 +207,7 @@ void pq_ctx_destroy(pq_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 4; ++i)
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
+    if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -596,6 +600,108 @@ int pq_delta_decode64(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t 
                       uint32_t *n_decoded, uint64_t *consumed)
 {
     return delta_host(ctx, PQ_KIND_DELTA64, src, src_len, n, dst, 8, n_decoded, consumed);
+}
+
+// ---- level post-processing ----------------------------------------------------
+
+static int ensure_work(pq_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->work_cap) return PQ_OK;
+    if (ctx->work) {
+        // work queued on the stream may still use the old block
+        PQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PQ_HIP(ctx, hipFree(ctx->work));
+        ctx->work = nullptr;
+        ctx->work_cap = 0;
+    }
+    const size_t cap = std::max<size_t>(bytes + bytes / 4, 1u << 20);
+    PQ_HIP(ctx, hipMalloc(&ctx->work, cap));
+    ctx->work_cap = cap;
+    return PQ_OK;
+}
+
+int pq_levels_pack_dev(pq_ctx *ctx, const int32_t *d_levels, uint64_t n, int bit_width, void *d_out,
+                       uint64_t out_bytes)
+{
+    if (!ctx || bit_width < 0 || bit_width > 16 || n > 0x7fffffffull) return PQ_ERR_BAD_ARGUMENT;
+    const uint64_t need = (n + 7) / 8 * (uint64_t)bit_width;
+    if (need == 0) return PQ_OK;
+    if (!d_levels || !d_out || (reinterpret_cast<uintptr_t>(d_out) & 3u) ||
+        (reinterpret_cast<uintptr_t>(d_levels) & 3u))
+        return PQ_ERR_BAD_ARGUMENT;
+    if (out_bytes < need) return PQ_ERR_OUT_OF_RANGE;
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    PQ_HIP(ctx, pq::launch_levels_pack(ctx->stream, d_levels, n, bit_width, static_cast<uint8_t *>(d_out)));
+    return PQ_OK;
+}
+
+int pq_levels_pack(pq_ctx *ctx, const int32_t *levels, uint64_t n, int bit_width, uint8_t *out,
+                   uint64_t out_bytes)
+{
+    if (!ctx || bit_width < 0 || bit_width > 16 || n > 0x7fffffffull) return PQ_ERR_BAD_ARGUMENT;
+    const uint64_t need = (n + 7) / 8 * (uint64_t)bit_width;
+    if (need == 0) return PQ_OK;
+    if (!levels || !out) return PQ_ERR_BAD_ARGUMENT;
+    if (out_bytes < need) return PQ_ERR_OUT_OF_RANGE;
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    int st = ensure_stage(ctx, 0, n * 4);
+    if (st == PQ_OK) st = ensure_stage(ctx, 1, need);
+    if (st != PQ_OK) return st;
+    PQ_HIP(ctx, hipMemcpyAsync(ctx->stage[0], levels, n * 4, hipMemcpyHostToDevice, ctx->stream));
+    st = pq_levels_pack_dev(ctx, static_cast<const int32_t *>(ctx->stage[0]), n, bit_width, ctx->stage[1], need);
+    if (st != PQ_OK) return st;
+    PQ_HIP(ctx, hipMemcpyAsync(out, ctx->stage[1], need, hipMemcpyDeviceToHost, ctx->stream));
+    PQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PQ_OK;
+}
+
+int pq_column_entries_dev(pq_ctx *ctx, const int32_t *d_def, const int32_t *d_rep, uint64_t n,
+                          uint32_t max_def, uint32_t max_rep, int repeated, uint32_t *d_offsets,
+                          void *d_validity, int32_t *d_entry_def, pq_entries_result *d_result)
+{
+    if (!ctx || !d_offsets || !d_result || n > 0x7fffffffull) return PQ_ERR_BAD_ARGUMENT;
+    if (max_def > 0xffffu || max_rep > 0xffffu) return PQ_ERR_BAD_ARGUMENT; // levels are uint16
+    if (n && (!d_def || !d_validity || !d_entry_def || (repeated && !d_rep))) return PQ_ERR_BAD_ARGUMENT;
+    if (reinterpret_cast<uintptr_t>(d_validity) & 3u) return PQ_ERR_BAD_ARGUMENT;
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    const int st = ensure_work(ctx, pq::entries_workspace_bytes(n) + 64);
+    if (st != PQ_OK) return st;
+    PQ_HIP(ctx, pq::launch_column_entries(ctx->stream, d_def, d_rep, n, (int32_t)max_def, (int32_t)max_rep,
+                                          repeated, d_offsets, static_cast<uint32_t *>(d_validity), d_entry_def,
+                                          d_result, ctx->work));
+    return PQ_OK;
+}
+
+int pq_column_entries(pq_ctx *ctx, const int32_t *def, const int32_t *rep, uint64_t n, uint32_t max_def,
+                      uint32_t max_rep, int repeated, uint32_t *offsets, uint8_t *validity,
+                      int32_t *entry_def, pq_entries_result *result)
+{
+    if (!ctx || !offsets || !result || n > 0x7fffffffull) return PQ_ERR_BAD_ARGUMENT;
+    if (n && (!def || !validity || !entry_def || (repeated && !rep))) return PQ_ERR_BAD_ARGUMENT;
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    // stage 0: def | rep, stage 1: offsets | entry_def, stage 2: validity | result
+    const size_t lv = (size_t)n * 4, vbytes = (size_t)((n + 31) / 32 * 4);
+    int st = ensure_stage(ctx, 0, 2 * lv + 16);
+    if (st == PQ_OK) st = ensure_stage(ctx, 1, 2 * lv + 16);
+    if (st == PQ_OK) st = ensure_stage(ctx, 2, vbytes + 64);
+    if (st != PQ_OK) return st;
+    uint8_t *s0 = static_cast<uint8_t *>(ctx->stage[0]), *s1 = static_cast<uint8_t *>(ctx->stage[1]),
+            *s2 = static_cast<uint8_t *>(ctx->stage[2]);
+    if (n) PQ_HIP(ctx, hipMemcpyAsync(s0, def, lv, hipMemcpyHostToDevice, ctx->stream));
+    if (n && repeated) PQ_HIP(ctx, hipMemcpyAsync(s0 + lv, rep, lv, hipMemcpyHostToDevice, ctx->stream));
+    pq_entries_result *d_res = reinterpret_cast<pq_entries_result *>(s2 + vbytes + ((16 - vbytes % 16) % 16));
+    st = pq_column_entries_dev(ctx, reinterpret_cast<const int32_t *>(s0), reinterpret_cast<const int32_t *>(s0 + lv),
+                               n, max_def, max_rep, repeated, reinterpret_cast<uint32_t *>(s1), s2,
+                               reinterpret_cast<int32_t *>(s1 + lv + 4), d_res);
+    if (st != PQ_OK) return st;
+    PQ_HIP(ctx, hipMemcpyAsync(result, d_res, sizeof *result, hipMemcpyDeviceToHost, ctx->stream));
+    PQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t ne = result->n_entries;
+    PQ_HIP(ctx, hipMemcpyAsync(offsets, s1, (ne + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ne) PQ_HIP(ctx, hipMemcpyAsync(entry_def, s1 + lv + 4, ne * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (vbytes) PQ_HIP(ctx, hipMemcpyAsync(validity, s2, vbytes, hipMemcpyDeviceToHost, ctx->stream));
+    PQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PQ_OK;
 }
 
 } // extern "C"

@@ -54,4 +54,13 @@ hipError_t launch_delta_serial(hipStream_t s, const pq_page_desc *d_descs, const
 
 constexpr uint32_t kDictLdsMax = 48u * 1024u;
 
+// Level post-processing (assemble.hip).  d_out: ceil(n / 8) * w bytes, 4-byte aligned.
+hipError_t launch_levels_pack(hipStream_t s, const int32_t *d_levels, uint64_t n, int w, uint8_t *d_out);
+// d_work: entries_workspace_bytes(n) bytes, 8-byte aligned; d_validity: 4 * ceil(n / 32) bytes.
+size_t entries_workspace_bytes(uint64_t n);
+hipError_t launch_column_entries(hipStream_t s, const int32_t *d_def, const int32_t *d_rep, uint64_t n,
+                                 int32_t max_def, int32_t max_rep, int repeated, uint32_t *d_offsets,
+                                 uint32_t *d_validity, int32_t *d_entry_def, pq_entries_result *d_result,
+                                 void *d_work);
+
 } // namespace pq

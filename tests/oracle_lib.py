@@ -188,6 +188,33 @@ def bool_plain_decode(src, n):
     return dict(status=st, values=out[:nd.value].copy(), n_decoded=nd.value, consumed=cons.value)
 
 
+def levels_pack(levels, w):
+    """PackedArray bytes of AppendSingle x n and, for n > 0, Flush."""
+    lv = np.ascontiguousarray(levels, dtype=np.int32)
+    out = np.zeros((lv.size + 7) // 8 * w + 1, dtype=np.uint8)
+    fn = lib().pqo_levels_pack
+    fn.restype = C.c_uint64
+    got = fn(_ptr(lv), C.c_uint64(lv.size), C.c_int(w), _ptr(out))
+    return out[:got].copy()
+
+
+def column_entries(def_levels, rep_levels, max_def, max_rep, repeated):
+    """ColumnStore.Get until "out of range" -> dict(n_entries, n_values, offsets, validity, entry_def)."""
+    d = np.ascontiguousarray(def_levels, dtype=np.int32)
+    r = np.ascontiguousarray(rep_levels if rep_levels is not None else np.zeros(d.size), dtype=np.int32)
+    n = d.size
+    offsets = np.zeros(n + 1, dtype=np.uint32)
+    validity = np.zeros((n + 31) // 32 * 4 + 4, dtype=np.uint8)
+    entry_def = np.zeros(max(n, 1), dtype=np.int32)
+    ne, nv = C.c_uint32(0), C.c_uint32(0)
+    fn = lib().pqo_column_entries
+    fn.restype = None
+    fn(_ptr(d), _ptr(r), C.c_uint64(n), C.c_int32(max_def), C.c_int32(max_rep), C.c_int(int(bool(repeated))),
+       _ptr(offsets), _ptr(validity), _ptr(entry_def), C.byref(ne), C.byref(nv))
+    return dict(n_entries=ne.value, n_values=nv.value, offsets=offsets[:ne.value + 1].copy(),
+                validity=validity[:(n + 31) // 32 * 4].copy(), entry_def=entry_def[:ne.value].copy())
+
+
 def hybrid_encode(values, w):
     v = np.ascontiguousarray(values, dtype=np.int32)
     cap = v.size * 5 + v.size // 8 + 64

@@ -8,6 +8,8 @@ device-resident, HIP-event timed.  Prints one JSON object per configuration.
   C4  nested V1 data pages: rep (w=1) + def (w=2) levels + dictionary values
   C2x INT64 delta at other miniblock widths / INT32 delta
   P   PLAIN int64 / int32 values, BOOLEAN PLAIN bits, BOOLEAN RLE runs
+  L   level post-processing over 100 M slots: column entries (validity, offsets, returned definition
+      levels) of a REPEATED and of an OPTIONAL column, PackedArray bytes of the levels
 """
 import argparse
 import json
@@ -232,6 +234,33 @@ def bench_plain(ctx, stream, pages, n, kind, es, label):
     plan.close()
 
 
+def bench_levels(ctx, stream, n):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(7)
+    with torch.cuda.stream(stream):
+        u = torch.rand(n, device=DEV, generator=g)
+        rep = (u < 0.75).to(torch.int32)                       # lists of 4 on average
+        u = torch.rand(n, device=DEV, generator=g)
+        deff = torch.where((u < 0.9) | (rep == 1), 3, (u * 29).to(torch.int32) % 3).to(torch.int32)
+        del u
+        offsets = torch.empty(n + 1, dtype=torch.int32, device=DEV)
+        validity = torch.empty((n + 31) // 32, dtype=torch.int32, device=DEV)
+        edef = torch.empty(n, dtype=torch.int32, device=DEV)
+        res = torch.zeros(4, dtype=torch.int32, device=DEV)
+        packed = torch.empty((n + 7) // 8 * 2 + 16, dtype=torch.uint8, device=DEV)
+    stream.synchronize()
+    for repeated, label in ((True, "REPEATED (max_rep 1, max_def 3)"), (False, "OPTIONAL (max_def 3)")):
+        fn = lambda: ctx.column_entries_dev(deff.data_ptr(), rep.data_ptr(), n, 3, 1, repeated, offsets.data_ptr(),
+                                            validity.data_ptr(), edef.data_ptr(), res.data_ptr())
+        t = timed(fn, stream, steps=6, warmup=1)
+        _, ne, nv, _ = res.cpu().tolist()
+        report("L column entries, %s" % label, n * (8 if repeated else 4), ne * 8 + 4 + (ne + 7) // 8, t,
+               {"slots": n, "entries": ne, "values": nv})
+    fn = lambda: ctx.levels_pack_dev(deff.data_ptr(), n, 2, packed.data_ptr(), packed.numel())
+    t = timed(fn, stream, steps=6, warmup=1)
+    report("L PackedArray bytes of int32 levels, width 2", n * 4, (n + 7) // 8 * 2, t, {"slots": n})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -260,6 +289,8 @@ def main():
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_PLAIN, 4, "P PLAIN int32")
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_BOOL_PLAIN, 4, "P BOOLEAN PLAIN")
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_BOOL_RLE, 4, "P BOOLEAN RLE (mean run 24)")
+    if want("levels"):
+        bench_levels(ctx, stream, 100_000_000)
     print("elapsed %.1fs" % (time.time() - t0), file=sys.stderr)
     ctx.close()
 
