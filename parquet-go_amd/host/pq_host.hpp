@@ -163,6 +163,27 @@ public:
         bufPos_ = 0;
     }
     const std::vector<uint8_t> &Data() const { return data_; }  // what Write() emits
+    // The array that AppendSingle x count would have built, from the bytes pq_levels_pack made of
+    // those values (ceil(count / 8) groups): the last 1..8 values go back into buf, the groups in
+    // front of them are the flushed data.
+    Error Adopt(int bitWidth, int count, const uint8_t *packed, size_t packedLen)
+    {
+        if (Error e = Reset(bitWidth)) return e;
+        if (count < 0 || packedLen < (size_t)((count + 7) / 8) * (size_t)bitWidth) return Error(PQ_ERR_BAD_ARGUMENT);
+        if (count == 0) return Error();
+        const size_t flushed = (size_t)((count - 1) / 8);
+        data_.assign(packed, packed + ((size_t)((count + 7) / 8)) * (size_t)bitWidth);
+        count_ = count;
+        for (int i = 0; i < 8; ++i) {
+            int32_t v = 0;
+            int pos = (int)flushed * 8 + i;
+            if (pos < count) At(pos, &v);  // still whole in data_ at this point
+            buf_[i] = v;
+        }
+        bufPos_ = count - (int)flushed * 8;
+        data_.resize(flushed * (size_t)bitWidth);
+        return Error();
+    }
 
 private:
     int count_ = 0, bw_ = 0, bufPos_ = 0;
@@ -663,6 +684,48 @@ inline ChunkData readPageData(Device &dev, const ColumnSpec &col, const std::vec
         out.numValues += res[i].not_null;
     }
     return out;
+}
+
+// ---- level post-processing ----------------------------------------------------------------
+// packLevels: the PackedArray the reference would hold after appending these levels one by one
+// (file-reader.go:285-296), packed on the device.
+inline Error packLevels(Device &dev, const int32_t *levels, size_t n, int bitWidth, PackedArray *out)
+{
+    std::vector<uint8_t> bytes(std::max<size_t>(1, (n + 7) / 8 * (size_t)bitWidth));
+    int st = pq_levels_pack(dev.ctx(), levels, n, bitWidth, bytes.data(), bytes.size());
+    check_library(st, "pq_levels_pack");
+    if (st != PQ_OK) return Error(st);
+    return out->Adopt(bitWidth, (int)n, bytes.data(), bytes.size());
+}
+
+// columnEntries: ColumnStore.Get (datastore/column.go:127-177) called to the end of the store, as
+// arrays.  Entry k is the k-th call: IsNull(k) == the call returned nil, entryDef[k] the definition
+// level it returned, and its values are values[offsets[k] .. offsets[k + 1]) of the column's dense
+// value array (one value for a column that is not REPEATED).
+struct ColumnEntries {
+    uint32_t numEntries = 0, numValues = 0;
+    std::vector<uint32_t> offsets;   // numEntries + 1
+    std::vector<uint8_t> validity;   // bit k, LSB first
+    std::vector<int32_t> entryDef;   // numEntries
+    bool IsNull(uint32_t k) const { return ((validity[k >> 3] >> (k & 7)) & 1) == 0; }
+};
+
+inline ColumnEntries columnEntries(Device &dev, const int32_t *dLevels, const int32_t *rLevels, size_t n,
+                                   uint16_t maxD, uint16_t maxR, bool repeated)
+{
+    ColumnEntries e;
+    e.offsets.resize(n + 1);
+    e.validity.resize((n + 31) / 32 * 4 + 4);
+    e.entryDef.resize(std::max<size_t>(n, 1));
+    pq_entries_result r;
+    int st = pq_column_entries(dev.ctx(), dLevels, rLevels, n, maxD, maxR, repeated ? 1 : 0, e.offsets.data(),
+                               e.validity.data(), e.entryDef.data(), &r);
+    check_library(st, "pq_column_entries");
+    e.numEntries = r.n_entries;
+    e.numValues = r.n_values;
+    e.offsets.resize((size_t)r.n_entries + 1);
+    e.entryDef.resize(r.n_entries);
+    return e;
 }
 
 }  // namespace pqhost

@@ -275,6 +275,66 @@ static void TestPackedArray()
     }
 }
 
+// ---- level post-processing: PackedArray built on the device, ColumnStore.Get as arrays --------
+static void TestLevelPostProcessing(Device &dev)
+{
+    for (int w : {1, 2, 3, 7, 16}) {
+        for (size_t n : {size_t(0), size_t(1), size_t(8), size_t(9), size_t(16), size_t(1000), size_t(70001)}) {
+            std::vector<int32_t> lv(n);
+            for (auto &v : lv) v = (int32_t)(rnd() & ((1u << w) - 1));
+            PackedArray want, got;
+            CHECK(!want.Reset(w));
+            want.AppendLevels(lv.data(), n);
+            CHECK(!packLevels(dev, lv.data(), n, w, &got));
+            CHECK_EQ(got.Count(), want.Count());
+            CHECK(got.Data() == want.Data());
+            bool same = true;
+            for (size_t i = 0; i < n; ++i) {
+                int32_t a = -1, b = -2;
+                same = same && !got.At((int)i, &a) && !want.At((int)i, &b) && a == b;
+            }
+            CHECK(same);
+            got.AppendSingle(1);  // the adopted array keeps growing like the original
+            want.AppendSingle(1);
+            got.Flush();
+            want.Flush();
+            CHECK(got.Data() == want.Data());
+        }
+    }
+    // [a b c] null [d e] of a REPEATED leaf
+    {
+        const int32_t def[] = {1, 1, 1, 0, 1, 1}, rep[] = {0, 1, 1, 0, 0, 1};
+        ColumnEntries e = columnEntries(dev, def, rep, 6, 1, 1, true);
+        CHECK_EQ(e.numEntries, 3);
+        CHECK_EQ(e.numValues, 5);
+        CHECK((e.offsets == std::vector<uint32_t>{0, 3, 3, 5}));
+        CHECK((e.entryDef == std::vector<int32_t>{1, 0, 1}));
+        CHECK(!e.IsNull(0) && e.IsNull(1) && !e.IsNull(2));
+    }
+    // against the oracle
+    for (int rp = 0; rp < 2; ++rp) {
+        const size_t n = 50021;
+        std::vector<int32_t> def(n), rep(n);
+        for (size_t i = 0; i < n; ++i) {
+            rep[i] = i ? (int32_t)(rnd() % 3) : 0;
+            def[i] = (rnd() % 10) < 7 ? 4 : (int32_t)(rnd() % 5);
+        }
+        ColumnEntries e = columnEntries(dev, def.data(), rep.data(), n, 4, 2, rp != 0);
+        std::vector<uint32_t> off(n + 1);
+        std::vector<uint8_t> val((n + 31) / 32 * 4);
+        std::vector<int32_t> ed(n);
+        uint32_t ne = 0, nv = 0;
+        pqo_column_entries(def.data(), rep.data(), n, 4, 2, rp, off.data(), val.data(), ed.data(), &ne, &nv);
+        CHECK_EQ(e.numEntries, ne);
+        CHECK_EQ(e.numValues, nv);
+        off.resize(ne + 1);
+        ed.resize(ne);
+        CHECK(e.offsets == off);
+        CHECK(e.entryDef == ed);
+        CHECK(std::equal(val.begin(), val.end(), e.validity.begin()));
+    }
+}
+
 // ---- types/float_test.go:120-171, types/double_test.go:120-171 -----------------------------------
 static void TestPlainDecoders(Device &dev)
 {
@@ -679,6 +739,7 @@ int main()
         {"TestDeltaBinaryPackDecoder64", [&] { TestDeltaBinaryPackDecoder<int64_t>(dev); }},
         {"TestPackedArray", [&] { TestPackedArray(); }},
         {"TestPlainDecoders", [&] { TestPlainDecoders(dev); }},
+        {"TestLevelPostProcessing", [&] { TestLevelPostProcessing(dev); }},
         {"TestDictDecoder_int32", [&] { TestDictDecoder<int32_t>(dev); }},
         {"TestDictDecoder_int64", [&] { TestDictDecoder<int64_t>(dev); }},
         {"TestDecodePackedArray", [&] { TestDecodePackedArray(dev); }},
