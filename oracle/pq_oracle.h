@@ -11,11 +11,13 @@
  * encoding/bitpacking32_test.go, encoding/bitpacking64_test.go,
  * encoding/hybrid-decoder_test.go, encoding/hybrid-encoder_test.go,
  * encoding/delta-binary-packed-decoder_test.go,
- * encoding/delta-binary-packed-encoder_test.go, encoding/packed-array_test.go).
+ * encoding/delta-binary-packed-encoder_test.go, encoding/packed-array_test.go,
+ * types/float_test.go, types/double_test.go).
  * The reference has no tests for types.DictDecoder, layout.decodePackedArray,
- * the V1/V2 page section order, multi-block delta streams or multi-run hybrid
- * decoding: for those the oracle follows the reference source line by line and
- * its parity is UNPINNED by any reference fixture.  The Go toolchain is not
+ * the V1/V2 page section order, multi-block delta streams, multi-run hybrid
+ * decoding, the int32 / int64 PLAIN decoders, the BOOLEAN decoders or
+ * ColumnStore.Get: for those the oracle follows the reference source line by
+ * line and its parity is UNPINNED by any reference fixture.  The Go toolchain is not
  * available, so the reference itself was never executed.
  */
 #ifndef PQ_ORACLE_H
