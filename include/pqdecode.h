@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 /* ---- status codes ---------------------------------------------------------
- * 1..15 are the reference's error classes; >= 100 are the library's own. */
+ * 1..18 are the reference's error classes; >= 100 are the library's own. */
 #define PQ_OK 0
 #define PQ_EOF 1                     /* io.EOF */
 #define PQ_UNEXPECTED_EOF 2          /* io.ErrUnexpectedEOF */
@@ -46,6 +46,9 @@ extern "C" {
 #define PQ_NOT_INITIALIZED 13        /* encoding/hybrid-decoder.go:79 */
 #define PQ_INVALID_STREAM 14         /* encoding/delta-binary-packed-decoder.go:154 */
 #define PQ_PAGE_VALUES_FAILED 15     /* layout/page-v1.go:104, layout/page-v2.go:137 */
+#define PQ_BYTE_ARRAY_NEGATIVE_LEN 16/* types/byte-array.go:210,326: make([]byte, ..) panics for a size < 0 */
+#define PQ_BYTE_ARRAY_COUNT_MISMATCH 17 /* types/byte-array.go:303: different number of suffixes and prefixes */
+#define PQ_BYTE_ARRAY_INVALID_PREFIX 18 /* types/byte-array.go:331: invalid prefix len in the stream */
 
 #define PQ_ERR_BAD_ARGUMENT 100
 #define PQ_ERR_HIP 101               /* a HIP runtime call failed; see pq_last_error */
@@ -126,6 +129,22 @@ int pq_bitunpack64(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, size_
                               Alone it is PQ_KIND_HYBRID with bit_width 1 and
                               PQ_FLAG_LENGTH_PREFIXED; as a value_kind it is the values section of
                               a BOOLEAN page in RLE encoding */
+#define PQ_KIND_DELTA_LENGTH_BA 11 /* ByteArrayDeltaLengthDecoder.Init + DecodeValues(dest[:n_values])
+                              (types/byte-array.go:168-219).  Output, both in the values buffer:
+                              the value bytes back to back at dst_off (at most src_len of them),
+                              and at dict_off (4-byte aligned) n_decoded + 1 uint32 offsets into
+                              them, offsets[0] = 0.  dict_len = the number of lengths the area at
+                              dict_off has room for (it holds dict_len + 1 words and serves as
+                              scratch): at least n_values, and at least the count the stream
+                              itself declares, else the page ends with PQ_ERR_OUT_OF_RANGE.
+                              src_len < 2^32.  Also a value_kind of data pages. */
+#define PQ_KIND_DELTA_BA 12 /* ByteArrayDeltaDecoder.Init + DecodeValues(dest[:n_values])
+                              (types/byte-array.go:279-348).  Output as for DELTA_LENGTH_BA, except
+                              that the values can be longer than the stream: dst_cap is the room
+                              at dst_off in bytes (PQ_ERR_OUT_OF_RANGE when they do not fit), and
+                              the area at dict_off holds 2 * dict_len + 1 words.  "invalid prefix
+                              len" reports n_decoded 0 like the reference (:330).  Also a
+                              value_kind of data pages. */
 
 #define PQ_FLAG_LENGTH_PREFIXED 1u /* HYBRID/LEVELS: InitSize (u32 LE length first) */
 #define PQ_FLAG_LEVELS_CONST 2u    /* LEVELS: ConstDecoder(0) (layout/chunk.go:111-124) */
@@ -141,7 +160,8 @@ typedef struct pq_page_desc {
     uint64_t rep_off;     /* byte offset of its int32 rep-level output (levels buffer) */
     uint64_t def_off;     /* byte offset of its int32 def-level output (levels buffer);
                              PQ_KIND_LEVELS writes its single stream here */
-    uint64_t dict_off;    /* byte offset of the dictionary in the dictionary buffer */
+    uint64_t dict_off;    /* byte offset of the dictionary in the dictionary buffer;
+                             DELTA_LENGTH_BA, DELTA_BA: of the offsets area in the values buffer */
     uint32_t n_values;    /* values to pull; for pages: header NumValues (level slots) */
     uint32_t bit_width;   /* HYBRID: w (0..32) */
     uint32_t max_rep;     /* pages: column max repetition level */
@@ -149,10 +169,12 @@ typedef struct pq_page_desc {
     uint32_t rep_len;     /* PAGE_V2: RepetitionLevelsByteLength */
     uint32_t def_len;     /* PAGE_V2: DefinitionLevelsByteLength */
     uint32_t value_kind;  /* pages: PQ_KIND_DICT, PQ_KIND_DELTA32, PQ_KIND_DELTA64, PQ_KIND_PLAIN,
-                             PQ_KIND_BOOL_PLAIN or PQ_KIND_BOOL_RLE */
+                             PQ_KIND_BOOL_PLAIN, PQ_KIND_BOOL_RLE, PQ_KIND_DELTA_LENGTH_BA or
+                             PQ_KIND_DELTA_BA */
     uint32_t elem_size;   /* DICT: bytes per dictionary entry (4 or 8); PLAIN: bytes per value */
-    uint32_t dict_len;    /* DICT: number of dictionary entries */
-    uint32_t reserved;
+    uint32_t dict_len;    /* DICT: number of dictionary entries; DELTA_LENGTH_BA, DELTA_BA: lengths
+                             the offsets area has room for */
+    uint32_t dst_cap;     /* DELTA_BA: bytes of room for the values at dst_off; else 0 */
 } pq_page_desc;
 
 typedef struct pq_page_result {
@@ -216,6 +238,19 @@ int pq_plain_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t el
                     void *dst, uint32_t *n_decoded, uint64_t *consumed);
 int pq_bool_plain_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n, int32_t *dst,
                          uint32_t *n_decoded, uint64_t *consumed);
+/* ByteArrayDeltaLengthDecoder.Init(reader) + DecodeValues(dest[:n]) (types/byte-array.go:168-219).
+ * offsets: n + 1 entries, value i is data[offsets[i] .. offsets[i + 1]); data: src_len bytes.
+ * *init_failed (may be NULL) tells an error of Init from one of DecodeValues. */
+int pq_delta_length_ba_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n,
+                              uint32_t *offsets, uint8_t *data, uint32_t *n_decoded,
+                              uint64_t *consumed, int *init_failed);
+/* ByteArrayDeltaDecoder.Init(reader) + DecodeValues(dest[:n]) (types/byte-array.go:279-348).
+ * offsets: n + 1 entries; data: data_cap bytes (< 2^32).  Returns PQ_ERR_OUT_OF_RANGE when the
+ * values need more than data_cap bytes; *data_need (may be NULL) then holds nothing useful, the
+ * caller retries with a larger area. */
+int pq_delta_ba_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n,
+                       uint32_t *offsets, uint8_t *data, size_t data_cap, uint32_t *n_decoded,
+                       uint64_t *consumed, int *init_failed);
 
 /* ---- Level post-processing: what the reference does with decoded levels, value by value ----
  *

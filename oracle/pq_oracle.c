@@ -789,6 +789,124 @@ int pqo_delta_decode64(const uint8_t *src, size_t src_len, uint32_t n, int64_t *
 }
 
 /* ------------------------------------------------------------------------- */
+/* DELTA_LENGTH_BYTE_ARRAY: types/byte-array.go:168-219                          */
+
+/* ByteArrayDeltaLengthDecoder.Init (:174-186) then DecodeValues(dest[:n]) (:188-219).
+ * Init decodes ALL ValuesCount lengths (decodeInt32, types/helpers.go:22-33); any error
+ * there fails Init.  next(): past the last length io.EOF; a negative length makes the
+ * reference panic in make([]byte, size) (PQO_BYTE_ARRAY_NEGATIVE_LEN here); then
+ * io.ReadFull of `size` bytes ("there is no byte left" wraps io.EOF / io.ErrUnexpectedEOF,
+ * reported as that class).  offsets[0] = 0, offsets[i + 1] = offsets[i] + len(value i);
+ * the value bytes are copied to data back to back. */
+/* Int32DeltaBPDecoder.Init + decodeInt32 over make([]int32, ValuesCount) (types/byte-array.go:177-185,
+ * :286-295; types/helpers.go:22-33): every declared length has to decode.  *lens is malloc'ed. */
+static int ba_read_lens(rd_t *r, int32_t **lens, uint32_t *count)
+{
+    delta_t d;
+    int st = delta_init(&d, r, 0);
+    uint32_t vc = st == PQO_OK ? (uint32_t)d.values_count : 0;
+    /* a stream cannot yield more lengths than this before it runs dry */
+    size_t cap = (size_t)vc < 32 * r->len + 256 ? (size_t)vc : 32 * r->len + 256;
+    *lens = (int32_t *)malloc((cap + 1) * sizeof **lens);
+    if (!*lens) abort();
+    for (uint32_t i = 0; st == PQO_OK && i < vc; i++) {
+        int64_t v;
+        st = delta_next(&d, &v);
+        if (st == PQO_OK && i < cap) (*lens)[i] = (int32_t)v;
+    }
+    delta_free(&d);
+    *count = vc;
+    return st;
+}
+
+int pqo_delta_length_ba_decode(const uint8_t *src, size_t src_len, uint32_t n, uint32_t *offsets,
+                               uint8_t *data, uint32_t *n_decoded, uint64_t *consumed,
+                               uint32_t *values_count, int *init_status)
+{
+    rd_t r = {src, src_len, 0};
+    int32_t *lens = NULL;
+    uint32_t vc = 0;
+    int st = ba_read_lens(&r, &lens, &vc);
+    if (values_count) *values_count = vc;
+    if (init_status) *init_status = st;
+    offsets[0] = 0;
+    uint32_t i = 0;
+    if (st == PQO_OK) {
+        for (; i < n; i++) {
+            if (i >= vc) { st = PQO_EOF; break; }
+            int32_t size = lens[i];
+            if (size < 0) { st = PQO_BYTE_ARRAY_NEGATIVE_LEN; break; }
+            st = rd_read_full(&r, data + offsets[i], (size_t)size);
+            if (st != PQO_OK) break;
+            offsets[i + 1] = offsets[i] + (uint32_t)size;
+        }
+    }
+    free(lens);
+    if (n_decoded) *n_decoded = i;
+    if (consumed) *consumed = r.pos;
+    return st;
+}
+
+/* ------------------------------------------------------------------------- */
+/* DELTA_BYTE_ARRAY: types/byte-array.go:279-348                                 */
+
+/* ByteArrayDeltaDecoder.Init (:285-313) then DecodeValues(dest[:n]) (:315-348).
+ * Init: the prefix lengths (all of them), then the suffix decoder's Init (all its lengths), then
+ * the two counts have to agree.  DecodeValues, per value: suffixDecoder.next() (EOF past the last,
+ * negative length panics, io.ReadFull); make([]byte, 0, prefixLen + len(suffix)) panics when that
+ * sum is negative; a prefix longer than the previous value is "invalid prefix len" and RETURNS
+ * COUNT 0 (:330); a negative prefix length that survives make() copies nothing (:338).
+ * data_cap: room at data; a value that does not fit ends the call with PQO_OUT_OF_RANGE_CAP
+ * (the library's limit, not the reference's).  offsets[i + 1] - offsets[i] = len(value i). */
+int pqo_delta_ba_decode(const uint8_t *src, size_t src_len, uint32_t n, uint32_t *offsets,
+                        uint8_t *data, uint64_t data_cap, uint32_t *n_decoded, uint64_t *consumed,
+                        uint32_t *values_count, int *init_status)
+{
+    rd_t r = {src, src_len, 0};
+    int32_t *plens = NULL, *slens = NULL;
+    uint32_t pc = 0, sc = 0;
+    int st = ba_read_lens(&r, &plens, &pc);
+    if (st == PQO_OK) {
+        /* the suffix decoder reads on from where the prefix lengths ended */
+        rd_t r2 = {src + r.pos, src_len - r.pos, 0};
+        st = ba_read_lens(&r2, &slens, &sc);
+        r.pos += r2.pos;
+        if (st == PQO_OK && pc != sc) st = PQO_BYTE_ARRAY_COUNT_MISMATCH;
+    }
+    if (values_count) *values_count = st == PQO_OK ? pc : 0;
+    if (init_status) *init_status = st;
+    offsets[0] = 0;
+    uint32_t i = 0;
+    if (st == PQO_OK) {
+        uint64_t prev_off = 0, prev_len = 0;
+        for (; i < n; i++) {
+            if (i >= sc) { st = PQO_EOF; break; }
+            int32_t size = slens[i];
+            if (size < 0) { st = PQO_BYTE_ARRAY_NEGATIVE_LEN; break; }
+            const uint8_t *suffix = r.p + r.pos;
+            st = rd_read_full(&r, NULL, (size_t)size);
+            if (st != PQO_OK) break;
+            int64_t plen = plens[i];
+            if (plen + size < 0) { st = PQO_BYTE_ARRAY_NEGATIVE_LEN; break; }
+            if ((int64_t)prev_len < plen) { st = PQO_BYTE_ARRAY_INVALID_PREFIX; i = 0; break; }
+            uint64_t keep = plen > 0 ? (uint64_t)plen : 0;
+            uint64_t off = offsets[i];
+            if (off + keep + (uint64_t)size > data_cap) { st = PQO_OUT_OF_RANGE_CAP; i = 0; break; }
+            memmove(data + off, data + prev_off, keep);
+            memcpy(data + off + keep, suffix, (size_t)size);
+            prev_off = off;
+            prev_len = keep + (uint64_t)size;
+            offsets[i + 1] = (uint32_t)(off + prev_len);
+        }
+    }
+    free(plens);
+    free(slens);
+    if (n_decoded) *n_decoded = i;
+    if (consumed) *consumed = r.pos;
+    return st;
+}
+
+/* ------------------------------------------------------------------------- */
 /* PLAIN fixed width and BOOLEAN PLAIN                                           */
 
 /* Int32/Int64/Float/DoublePlainDecoder.DecodeValues (types/int32.go:56-72,
@@ -913,6 +1031,20 @@ void pqo_page_read(const pqo_page_in *in, int32_t *rep, int32_t *def, void *valu
     case PQO_VALUES_BOOL_RLE: /* NewHybridDecoder(1, false).InitSize(reader), types/boolean.go:177-181 */
         st = hybrid_init_size(&brle, &r, 0);
         break;
+    case PQO_VALUES_DELTA_LENGTH_BA: { /* Init decodes every length (types/byte-array.go:174-186) */
+        uint32_t off0[1];
+        int init = PQO_OK;
+        (void)pqo_delta_length_ba_decode(r.p + r.pos, r.len - r.pos, 0, off0, NULL, NULL, NULL, NULL, &init);
+        st = init;
+        break;
+    }
+    case PQO_VALUES_DELTA_BA: { /* Init decodes both length streams (types/byte-array.go:285-313) */
+        uint32_t off0[1];
+        int init = PQO_OK;
+        (void)pqo_delta_ba_decode(r.p + r.pos, r.len - r.pos, 0, off0, NULL, 0, NULL, NULL, NULL, &init);
+        st = init;
+        break;
+    }
     default: st = PQO_NOT_INITIALIZED; break;
     }
     if (st != PQO_OK) {
@@ -943,6 +1075,15 @@ void pqo_page_read(const pqo_page_in *in, int32_t *rep, int32_t *def, void *valu
             st = pqo_plain_decode(r.p + r.pos, r.len - r.pos, in->elem_size, nn, values, &cnt, NULL);
         } else if (in->value_kind == PQO_VALUES_BOOL_PLAIN) {
             st = pqo_bool_plain_decode(r.p + r.pos, r.len - r.pos, nn, (int32_t *)values, &cnt, NULL);
+        } else if (in->value_kind == PQO_VALUES_DELTA_LENGTH_BA) {
+            /* values: (num_values + 1) uint32 offsets, then the value bytes */
+            uint32_t *offs = (uint32_t *)values;
+            st = pqo_delta_length_ba_decode(r.p + r.pos, r.len - r.pos, nn, offs,
+                                            (uint8_t *)(offs + in->num_values + 1), &cnt, NULL, NULL, NULL);
+        } else if (in->value_kind == PQO_VALUES_DELTA_BA) {
+            uint32_t *offs = (uint32_t *)values;
+            st = pqo_delta_ba_decode(r.p + r.pos, r.len - r.pos, nn, offs, (uint8_t *)(offs + in->num_values + 1),
+                                     in->data_cap, &cnt, NULL, NULL, NULL);
         } else if (in->value_kind == PQO_VALUES_BOOL_RLE) {
             for (; cnt < nn; cnt++) { /* dest[i] = n == 1, types/boolean.go:186-193 */
                 int32_t v;

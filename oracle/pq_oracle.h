@@ -48,7 +48,11 @@ enum pqo_status {
     PQO_DICT_INVALID_INDEX = 12,     /* types/dict.go:104 (also the negative-key panic) */
     PQO_NOT_INITIALIZED = 13,        /* "reader is not initialized"     hybrid-decoder.go:79 */
     PQO_INVALID_STREAM = 14,         /* "invalid stream"                delta-binary-packed-decoder.go:154 */
-    PQO_PAGE_VALUES_FAILED = 15      /* "read values from page failed"  page-v1.go:104, page-v2.go:137 */
+    PQO_PAGE_VALUES_FAILED = 15,     /* "read values from page failed"  page-v1.go:104, page-v2.go:137 */
+    PQO_BYTE_ARRAY_NEGATIVE_LEN = 16,/* make([]byte, size) with size < 0 panics, types/byte-array.go:210,326 */
+    PQO_BYTE_ARRAY_COUNT_MISMATCH = 17, /* "bytearray/delta: different number of suffixes and prefixes" byte-array.go:303 */
+    PQO_BYTE_ARRAY_INVALID_PREFIX = 18, /* "invalid prefix len in the stream"  byte-array.go:331 */
+    PQO_OUT_OF_RANGE_CAP = 103       /* not the reference's: the caller's output area is too small */
 };
 
 /* Stage of a data-page read at which an error surfaced (page-v1.go, page-v2.go). */
@@ -68,7 +72,11 @@ enum pqo_value_kind {
     PQO_VALUES_DELTA64 = 3, /* types.Int64DeltaBPDecoder */
     PQO_VALUES_PLAIN = 4,   /* Int32/Int64/Float/DoublePlainDecoder, elem_size bytes per value */
     PQO_VALUES_BOOL_PLAIN = 5, /* BooleanPlainDecoder, one int32 0/1 per value */
-    PQO_VALUES_BOOL_RLE = 6    /* BooleanRLEDecoder (types/boolean.go:173-196), one int32 0/1 per value */
+    PQO_VALUES_BOOL_RLE = 6,   /* BooleanRLEDecoder (types/boolean.go:173-196), one int32 0/1 per value */
+    PQO_VALUES_DELTA_LENGTH_BA = 7,/* ByteArrayDeltaLengthDecoder (types/byte-array.go:168-219); values =
+                                      (num_values + 1) uint32 offsets followed by the value bytes */
+    PQO_VALUES_DELTA_BA = 8        /* ByteArrayDeltaDecoder (types/byte-array.go:279-348); same layout,
+                                      data_cap bytes of room behind the offsets */
 };
 
 /* ---- fixed-width bit packing (encoding/bitpacking32.go, bitpacking64.go) ---- */
@@ -138,6 +146,7 @@ typedef struct pqo_page_in {
     uint32_t elem_size;      /* dictionary entry bytes (DICT) */
     const void *dict;
     uint32_t dict_len;
+    uint64_t data_cap;       /* DELTA_BA: bytes of room for the values behind the offsets */
 } pqo_page_in;
 
 typedef struct pqo_page_out {
@@ -152,6 +161,19 @@ typedef struct pqo_page_out {
 /* rep/def: num_values int32 each; values: num_values entries of the value type. */
 void pqo_page_read(const pqo_page_in *in, int32_t *rep, int32_t *def, void *values,
                    pqo_page_out *out);
+
+/* ---- DELTA_LENGTH_BYTE_ARRAY (types/byte-array.go:168-219): Init + DecodeValues(dest[:n]).
+ * offsets: n + 1; data: src_len bytes.  *init_status != 0: Init failed (n_decoded 0). */
+int pqo_delta_length_ba_decode(const uint8_t *src, size_t src_len, uint32_t n, uint32_t *offsets,
+                               uint8_t *data, uint32_t *n_decoded, uint64_t *consumed,
+                               uint32_t *values_count, int *init_status);
+
+/* ---- DELTA_BYTE_ARRAY (types/byte-array.go:279-348): Init + DecodeValues(dest[:n]).
+ * offsets: n + 1; data: data_cap bytes (PQO_OUT_OF_RANGE_CAP when the values do not fit).
+ * "invalid prefix len" reports n_decoded 0 as the reference does (:330). */
+int pqo_delta_ba_decode(const uint8_t *src, size_t src_len, uint32_t n, uint32_t *offsets,
+                        uint8_t *data, uint64_t data_cap, uint32_t *n_decoded, uint64_t *consumed,
+                        uint32_t *values_count, int *init_status);
 
 /* ---- level post-processing ----
  * pqo_levels_pack: PackedArray bytes (encoding/packed-array.go:47-55,118-125) of n levels at

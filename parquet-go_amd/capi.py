@@ -20,7 +20,8 @@ INVALID_STREAM, PAGE_VALUES_FAILED = 14, 15
 ERR_BAD_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_OUT_OF_RANGE = 100, 101, 102, 103
 
 KIND_HYBRID, KIND_DICT, KIND_LEVELS, KIND_DELTA32, KIND_DELTA64, KIND_PAGE_V1, KIND_PAGE_V2 = range(1, 8)
-KIND_PLAIN, KIND_BOOL_PLAIN, KIND_BOOL_RLE = 8, 9, 10
+KIND_PLAIN, KIND_BOOL_PLAIN, KIND_BOOL_RLE, KIND_DELTA_LENGTH_BA, KIND_DELTA_BA = 8, 9, 10, 11, 12
+BYTE_ARRAY_NEGATIVE_LEN, BYTE_ARRAY_COUNT_MISMATCH, BYTE_ARRAY_INVALID_PREFIX = 16, 17, 18
 FLAG_LENGTH_PREFIXED, FLAG_LEVELS_CONST, FLAG_NO_INIT = 1, 2, 4
 OPT_DELTA_WAVE_MIN_PAGES = 1
 OPT_HYBRID_WAVE_MIN_PAGES = 2
@@ -35,6 +36,7 @@ EXPORTS = [
     "pq_hybrid_decode", "pq_dict_decode", "pq_levels_decode", "pq_delta_decode32",
     "pq_delta_decode64", "pq_plain_decode", "pq_bool_plain_decode",
     "pq_levels_pack_dev", "pq_levels_pack", "pq_column_entries_dev", "pq_column_entries",
+    "pq_delta_length_ba_decode", "pq_delta_ba_decode",
 ]
 
 
@@ -44,7 +46,7 @@ class PageDesc(C.Structure):
                 ("def_off", C.c_uint64), ("dict_off", C.c_uint64), ("n_values", C.c_uint32),
                 ("bit_width", C.c_uint32), ("max_rep", C.c_uint32), ("max_def", C.c_uint32),
                 ("rep_len", C.c_uint32), ("def_len", C.c_uint32), ("value_kind", C.c_uint32),
-                ("elem_size", C.c_uint32), ("dict_len", C.c_uint32), ("reserved", C.c_uint32)]
+                ("elem_size", C.c_uint32), ("dict_len", C.c_uint32), ("dst_cap", C.c_uint32)]
 
 
 class PageResult(C.Structure):
@@ -63,7 +65,7 @@ DESC_DTYPE = np.dtype([("kind", "<u4"), ("flags", "<u4"), ("src_off", "<u8"), ("
                        ("dict_off", "<u8"), ("n_values", "<u4"), ("bit_width", "<u4"),
                        ("max_rep", "<u4"), ("max_def", "<u4"), ("rep_len", "<u4"),
                        ("def_len", "<u4"), ("value_kind", "<u4"), ("elem_size", "<u4"),
-                       ("dict_len", "<u4"), ("reserved", "<u4")])
+                       ("dict_len", "<u4"), ("dst_cap", "<u4")])
 RESULT_DTYPE = np.dtype([("status", "<i4"), ("stage", "<i4"), ("detail", "<i4"),
                          ("n_decoded", "<u4"), ("not_null", "<u4"), ("n_levels", "<u4"),
                          ("consumed", "<u8")])
@@ -129,6 +131,10 @@ def load():
         for name in ("pq_column_entries_dev", "pq_column_entries"):
             getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pq_delta_length_ba_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pq_delta_ba_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pq_bool_plain_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         _lib = lib
@@ -271,6 +277,32 @@ class Context:
         return results, values, levels
 
     # ---- device-resident entry points (raw device pointers) ----
+    def delta_length_ba_decode(self, src, n):
+        """ByteArrayDeltaLengthDecoder.Init + DecodeValues(dest[:n]) -> dict(status, init_failed, n_decoded,
+        consumed, offsets[:n_decoded + 1], data[:offsets[-1]])."""
+        s = _np_u8(src)
+        offsets = np.zeros(n + 1, dtype=np.uint32)
+        data = np.zeros(max(s.size, 1), dtype=np.uint8)
+        nd, cons, bad = C.c_uint32(0), C.c_uint64(0), C.c_int(0)
+        st = self._check(self._lib.pq_delta_length_ba_decode(self._h, _ptr(s), s.size, int(n), _ptr(offsets),
+                                                             _ptr(data), C.byref(nd), C.byref(cons), C.byref(bad)),
+                         "delta length byte array")
+        return dict(status=st, init_failed=bad.value, n_decoded=nd.value, consumed=cons.value,
+                    offsets=offsets[:nd.value + 1].copy(), data=data[:int(offsets[nd.value])].copy())
+
+    def delta_ba_decode(self, src, n, data_cap):
+        """ByteArrayDeltaDecoder.Init + DecodeValues(dest[:n]) with room for data_cap value bytes -> the same
+        dictionary as delta_length_ba_decode."""
+        s = _np_u8(src)
+        offsets = np.zeros(n + 1, dtype=np.uint32)
+        data = np.zeros(max(int(data_cap), 1), dtype=np.uint8)
+        nd, cons, bad = C.c_uint32(0), C.c_uint64(0), C.c_int(0)
+        st = self._check(self._lib.pq_delta_ba_decode(self._h, _ptr(s), s.size, int(n), _ptr(offsets), _ptr(data),
+                                                      int(data_cap), C.byref(nd), C.byref(cons), C.byref(bad)),
+                         "delta byte array")
+        return dict(status=st, init_failed=bad.value, n_decoded=nd.value, consumed=cons.value,
+                    offsets=offsets[:nd.value + 1].copy(), data=data[:int(offsets[nd.value])].copy())
+
     def levels_pack(self, levels, bit_width):
         """PackedArray bytes of `levels` (AppendSingle x n, Flush): ceil(n / 8) * bit_width bytes."""
         lv = np.ascontiguousarray(levels, dtype=np.int32)

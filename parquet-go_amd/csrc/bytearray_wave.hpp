@@ -1,0 +1,380 @@
+// bytearray_wave.hpp — DELTA_LENGTH_BYTE_ARRAY by one wave.
+//
+// Reference: ByteArrayDeltaLengthDecoder (types/byte-array.go:168-219).  Init decodes ALL the
+// lengths the stream declares (an Int32 DELTA_BINARY_PACKED stream; any error there fails Init)
+// and leaves the reader at the first value byte; DecodeValues then cuts value after value off
+// the bytes that follow.  Here: the lengths through delta_wave into the caller's offsets area,
+// an exclusive scan of them in place, one contiguous copy of the value bytes.
+#pragma once
+
+#include "delta_stream.hpp"
+#include "delta_wave.hpp"
+
+namespace pq {
+
+__device__ __forceinline__ uint64_t wave_readlane_u64(uint64_t x, uint32_t l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, (int)l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), (int)l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+struct ByteArrayResult {
+    int32_t status;
+    uint32_t n_decoded;
+    uint64_t consumed;
+    uint32_t init_failed;
+};
+
+// The value count a DELTA_BINARY_PACKED header declares, read straight from memory (only used in
+// front of the one-lane decoder).  false: the header does not parse that far.
+__device__ __forceinline__ bool delta_peek_total(const uint8_t *S, int64_t len, uint32_t *total)
+{
+    int64_t pos = 0;
+    uint64_t v[3];
+    for (int k = 0; k < 3; ++k) {
+        uint64_t x = 0;
+        int shift = 0;
+        while (true) {
+            if (pos >= len || shift > 63) return false;
+            const uint8_t b = S[pos++];
+            x |= (uint64_t)(b & 0x7fu) << shift;
+            shift += 7;
+            if ((b & 0x80u) == 0) break;
+        }
+        v[k] = x;
+    }
+    *total = v[2] > 0xffffffffull ? 0xffffffffu : (uint32_t)v[2];
+    return true;
+}
+
+// dst[0, n) = src[0, n): any alignment on either side, 4 bytes per lane and step.
+__device__ __forceinline__ void wave_copy_bytes(uint8_t *dst, const uint8_t *src, uint64_t n, int lane)
+{
+    if (n == 0) return;
+    // bytes in front of the first 4-byte aligned destination address
+    const uint32_t head = (uint32_t)min((uint64_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u), n);
+    if ((uint32_t)lane < head) dst[lane] = src[lane];
+    dst += head;
+    src += head;
+    n -= head;
+    const uint64_t words = n >> 2;
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u) * 8u;
+    const uint32_t *s32 = reinterpret_cast<const uint32_t *>(reinterpret_cast<uintptr_t>(src) & ~(uintptr_t)3);
+    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
+    if (sh == 0u) {
+        for (uint64_t i = (uint64_t)lane; i < words; i += kWave) __builtin_nontemporal_store(s32[i], d32 + i);
+    } else {
+        // word i of the destination straddles aligned source words i and i + 1; the second one
+        // holds at least one byte of the source (n >= 4 (i + 1)), so both lie inside its pages
+        for (uint64_t i = (uint64_t)lane; i < words; i += kWave)
+            __builtin_nontemporal_store(__builtin_amdgcn_alignbit(s32[i + 1], s32[i], sh), d32 + i);
+    }
+    const uint32_t tail = (uint32_t)(n & 3u);
+    if ((uint32_t)lane < tail) dst[4 * words + lane] = src[4 * words + lane];
+}
+
+// Every length an INT32 DELTA_BINARY_PACKED stream declares, into area[0, total): what
+// Int32DeltaBPDecoder.Init + decodeInt32(make([]int32, ValuesCount)) leave behind
+// (types/byte-array.go:177-185, :286-295).  ok: Init succeeded; otherwise status is its error
+// (kOverCap: the stream declares more than cap lengths and nothing was decoded).
+struct ByteArrayLens {
+    int32_t status;
+    uint32_t total;
+    uint64_t consumed;
+    bool ok;
+};
+
+__device__ __forceinline__ ByteArrayLens ba_lengths_wave(uint32_t *window, const uint8_t *S, int64_t len, uint32_t cap,
+                                                         uint32_t *area, int lane)
+{
+    WaveDeltaResult lr = delta_wave<uint32_t>(window, S, len, 0x7fffffffu, area, lane, cap);
+    if (lr.status == kNeedGeneric) {
+        // a block layout other than 128 / 4: one lane decodes the lengths
+        uint32_t total = 0;
+        const bool parsed = delta_peek_total(S, len, &total);
+        if (parsed && total > cap) {
+            lr.status = kOverCap;
+        } else {
+            DeltaResult sr{PQ_OK, 0, 0, 0};
+            if (lane == 0) sr = delta_serial<uint32_t>(S, len, parsed ? total : 0u, area);
+            lr.status = (int32_t)uni((uint32_t)sr.status);
+            lr.n_decoded = uni(sr.n_decoded);
+            lr.consumed = ((uint64_t)uni((uint32_t)(sr.consumed >> 32)) << 32) | uni((uint32_t)sr.consumed);
+            lr.init_failed = uni(sr.init_failed);
+            lr.total = parsed ? total : 0u;
+        }
+    }
+    ByteArrayLens r;
+    r.status = lr.status;
+    r.total = lr.total;
+    r.consumed = lr.consumed;
+    // asking for more than there are ends in io.EOF right behind the last one, which is not an
+    // error of Init
+    r.ok = lr.status != kOverCap && !lr.init_failed && lr.n_decoded == lr.total &&
+           (lr.status == PQ_OK || lr.status == PQ_EOF);
+    return r;
+}
+
+// Decode DecodeValues(dest[:n]) of a fresh decoder over [S, S + len).
+//   area: cap + 1 uint32, 4-byte aligned; on return area[0..n_decoded] are the value offsets
+//         (area[0] = 0) and area beyond them is scratch.
+//   data: the value bytes, back to back (at most len of them).
+// A stream declaring more than cap lengths is refused with PQ_ERR_OUT_OF_RANGE.
+__device__ __forceinline__ ByteArrayResult delta_length_ba_wave(uint32_t *window, const uint8_t *S, int64_t len,
+                                                                uint32_t n, uint32_t cap, uint32_t *area, uint8_t *data,
+                                                                int lane)
+{
+    ByteArrayResult res{PQ_OK, 0, 0, 0};
+    const ByteArrayLens lr = ba_lengths_wave(window, S, len, cap, area, lane);
+    if (!lr.ok) {
+        res.status = lr.status == kOverCap ? PQ_ERR_OUT_OF_RANGE : lr.status;
+        res.init_failed = 1;
+        res.consumed = lr.status == kOverCap ? 0 : lr.consumed;
+        return res;
+    }
+    const uint32_t total = lr.total;
+    // the lengths went out as plain and non-temporal stores: make them visible to the loads below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
+    const uint64_t avail = (uint64_t)len - lr.consumed;  // bytes behind the lengths
+    const uint32_t m = min(n, total);
+    uint64_t carry = 0;
+    uint32_t done = 0;
+    int32_t status = PQ_OK;
+    // offsets[i + 1] takes the place of length i + 1: a chunk's lengths are loaded before the
+    // chunk in front of it stores
+    auto load_len = [&](uint32_t i) -> int32_t {
+        return i < m ? (int32_t)__hip_atomic_load(area + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    };
+    int32_t cur = load_len((uint32_t)lane);
+    for (uint32_t base = 0; base < m; base += kWave) {
+        const int32_t next = load_len(base + kWave + (uint32_t)lane);
+        const uint32_t i = base + (uint32_t)lane;
+        const bool live = i < m;
+        const bool neg = live && cur < 0;
+        const uint64_t incl = carry + wave_scan_u64(live && !neg ? (uint64_t)(uint32_t)cur : 0ull);
+        // io.ReadFull of this value fails when the bytes run out
+        const bool fail = neg || (live && incl > avail);
+        const uint64_t fm = __builtin_amdgcn_ballot_w64(fail);
+        const uint32_t ok_lanes = fm ? (uint32_t)__builtin_ctzll(fm) : (uint32_t)kWave;
+        if (live && (uint32_t)lane < ok_lanes) area[i + 1] = (uint32_t)incl;
+        if (base == 0 && lane == 0) area[0] = 0;
+        if (fm != 0ull) {
+            // everything in front of the failing value is good
+            const uint64_t before = ok_lanes ? wave_readlane_u64(incl, ok_lanes - 1u) : carry;
+            const bool was_neg = ((__builtin_amdgcn_ballot_w64(neg) >> ok_lanes) & 1ull) != 0ull;
+            done = base + ok_lanes;
+            status = was_neg ? PQ_BYTE_ARRAY_NEGATIVE_LEN : (before == avail ? PQ_EOF : PQ_UNEXPECTED_EOF);
+            // a negative length panics before anything is read; a short read takes what is left
+            res.consumed = lr.consumed + (was_neg ? before : avail);
+            carry = before;
+            break;
+        }
+        carry = wave_last_u64(incl);
+        done = min(base + (uint32_t)kWave, m);
+        cur = next;
+    }
+    if (m == 0 && lane == 0) area[0] = 0;
+    if (status == PQ_OK) {
+        res.consumed = lr.consumed + carry;
+        if (n > total) status = PQ_EOF;  // next() past the last length (:205-207)
+    }
+    wave_copy_bytes(data, S + lr.consumed, carry, lane);
+    res.status = status;
+    res.n_decoded = done;
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DELTA_BYTE_ARRAY.  Reference: ByteArrayDeltaDecoder (types/byte-array.go:279-348).  Init decodes
+// all prefix lengths, then the suffix decoder's Init all suffix lengths; the counts have to agree.
+// Value i = the first prefixLen[i] bytes of value i - 1, then suffix i.
+//
+// Which byte of the suffix area ends up at position j of value i does not need the values in
+// front of it: it is byte j - p[k] of suffix k for the nearest k <= i with p[k] <= j.  A batch of
+// 64 values (one per lane) finds that k with one ballot per byte position; positions no value of
+// the batch starts a suffix at come from the batch in front (its last value, already in `data`).
+
+constexpr uint32_t kBaBatchMaxLen = 192;  // batches with a longer value go value by value
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = max(x, (uint32_t)__shfl_xor((int)x, o));
+    return x;
+}
+
+__device__ __forceinline__ void workgroup_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+//   area: 2 * cap + 1 uint32, 4-byte aligned: area[0..n_decoded] receive the value offsets, the
+//         rest is scratch (the prefix lengths live in its upper half).
+//   data: data_cap bytes for the values, back to back.  Values that do not fit: PQ_ERR_OUT_OF_RANGE.
+__device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const uint8_t *S, int64_t len, uint32_t n,
+                                                         uint32_t cap, uint32_t *area, uint8_t *data, uint64_t data_cap,
+                                                         int lane)
+{
+    ByteArrayResult res{PQ_OK, 0, 0, 0};
+    uint32_t *P = area + cap + 1;
+    const ByteArrayLens lp = ba_lengths_wave(window, S, len, cap, P, lane);
+    if (!lp.ok) {
+        res.status = lp.status == kOverCap ? PQ_ERR_OUT_OF_RANGE : lp.status;
+        res.init_failed = 1;
+        res.consumed = lp.status == kOverCap ? 0 : lp.consumed;
+        return res;
+    }
+    const ByteArrayLens ls = ba_lengths_wave(window, S + lp.consumed, len - (int64_t)lp.consumed, cap, area, lane);
+    const uint64_t init_consumed = lp.consumed + ls.consumed;
+    if (!ls.ok) {
+        res.status = ls.status == kOverCap ? PQ_ERR_OUT_OF_RANGE : ls.status;
+        res.init_failed = 1;
+        res.consumed = ls.status == kOverCap ? 0 : init_consumed;
+        return res;
+    }
+    if (lp.total != ls.total) {  // :301-308
+        res.status = PQ_BYTE_ARRAY_COUNT_MISMATCH;
+        res.init_failed = 1;
+        res.consumed = init_consumed;
+        return res;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+
+    // ---- pass A: lengths -> offsets, and the first value DecodeValues fails at ----
+    const uint32_t total = ls.total;
+    const uint64_t avail = (uint64_t)len - init_consumed;  // suffix bytes
+    const uint32_t m = min(n, total);
+    uint64_t scarry = 0, ocarry = 0;
+    uint32_t prev_carry = 0, done = 0;
+    int32_t status = PQ_OK;
+    auto load_word = [&](const uint32_t *base, uint32_t i) -> int32_t {
+        return i < m ? (int32_t)__hip_atomic_load(base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    };
+    int32_t cur_s = load_word(area, (uint32_t)lane);
+    res.consumed = init_consumed;
+    for (uint32_t base = 0; base < m; base += kWave) {
+        // offsets[i + 1] takes the place of suffix length i + 1: load the next batch first
+        const int32_t next_s = load_word(area, base + kWave + (uint32_t)lane);
+        const uint32_t i = base + (uint32_t)lane;
+        const bool live = i < m;
+        const int32_t s = cur_s, p = load_word(P, i);
+        const bool neg_s = live && s < 0;  // make([]byte, size) panics (:210)
+        const uint64_t sincl = scarry + wave_scan_u64(live && !neg_s ? (uint64_t)(uint32_t)s : 0ull);
+        const bool rd_fail = live && !neg_s && sincl > avail;                // io.ReadFull (:212)
+        const bool neg_cap = live && !neg_s && (int64_t)p + (int64_t)s < 0;  // make(.., 0, prefixLen + len(suffix)) (:326)
+        const uint32_t pz = p > 0 ? (uint32_t)p : 0u;
+        const uint32_t vlen = live && !neg_s && !neg_cap ? pz + (uint32_t)s : 0u;
+        const uint32_t up = (uint32_t)__shfl_up((int)vlen, 1);
+        const uint32_t prev_len = lane == 0 ? prev_carry : up;
+        const bool bad_p = live && (int64_t)prev_len < (int64_t)p;  // :328-336
+        const uint64_t fm = __builtin_amdgcn_ballot_w64(neg_s || rd_fail || neg_cap || bad_p);
+        const uint32_t ok_lanes = fm ? (uint32_t)__builtin_ctzll(fm) : (uint32_t)kWave;
+        const uint64_t oincl = ocarry + wave_scan_u64((uint64_t)vlen);
+        if (live && (uint32_t)lane < ok_lanes) area[i + 1] = (uint32_t)oincl;
+        if (fm != 0ull) {
+            const uint32_t f = ok_lanes;
+            const uint64_t s_before = f ? wave_readlane_u64(sincl, f - 1u) : scarry;
+            const uint64_t s_at = wave_readlane_u64(sincl, f);
+            ocarry = f ? wave_readlane_u64(oincl, f - 1u) : ocarry;
+            done = base + f;
+            if ((__builtin_amdgcn_ballot_w64(neg_s) >> f) & 1ull) {
+                status = PQ_BYTE_ARRAY_NEGATIVE_LEN;
+                res.consumed = init_consumed + s_before;
+            } else if ((__builtin_amdgcn_ballot_w64(rd_fail) >> f) & 1ull) {
+                status = s_before == avail ? PQ_EOF : PQ_UNEXPECTED_EOF;
+                res.consumed = init_consumed + avail;
+            } else if ((__builtin_amdgcn_ballot_w64(neg_cap) >> f) & 1ull) {
+                status = PQ_BYTE_ARRAY_NEGATIVE_LEN;
+                res.consumed = init_consumed + s_at;
+            } else {
+                status = PQ_BYTE_ARRAY_INVALID_PREFIX;
+                res.consumed = init_consumed + s_at;
+            }
+            break;
+        }
+        scarry = wave_last_u64(sincl);
+        ocarry = wave_last_u64(oincl);
+        prev_carry = (uint32_t)__builtin_amdgcn_readlane((int)vlen, 63);
+        done = min(base + (uint32_t)kWave, m);
+        cur_s = next_s;
+        res.consumed = init_consumed + scarry;
+    }
+    if (lane == 0) area[0] = 0;
+    if (ocarry > data_cap) {
+        res.status = PQ_ERR_OUT_OF_RANGE;
+        res.n_decoded = 0;
+        return res;
+    }
+    if (status == PQ_OK && n > total) status = PQ_EOF;  // next() past the last length (:205-207)
+    res.status = status;
+    res.n_decoded = status == PQ_BYTE_ARRAY_INVALID_PREFIX ? 0u : done;  // "return 0, err" (:330)
+    if (res.n_decoded == 0) return res;
+    done = res.n_decoded;
+
+    // ---- pass B: the bytes ----
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const uint8_t *SUF = S + init_consumed;
+    uint32_t sc = 0;        // suffix bytes in front of this batch
+    uint32_t prev_off = 0;  // offset of the value in front of this batch
+    for (uint32_t base = 0; base < done; base += kWave) {
+        const uint32_t i = base + (uint32_t)lane;
+        const bool live = i < done;
+        const uint32_t o0 = live ? __hip_atomic_load(area + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t o1 = live ? __hip_atomic_load(area + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const int32_t pr = live ? (int32_t)P[i] : 0;
+        const uint32_t p = live ? (pr > 0 ? (uint32_t)pr : 0u) : 0x7fffffffu;
+        const uint32_t vlen = o1 - o0;
+        const uint32_t s = live ? vlen - p : 0u;
+        const uint32_t sincl = sc + wave_scan_u32(s);
+        const uint32_t soff = sincl - s;
+        const uint32_t maxlen = wave_max_u32(vlen);
+        if (maxlen <= kBaBatchMaxLen) {
+            const uint32_t srcbase = soff - p;  // suffix-area offset of this value's position 0
+            const uint64_t below = (2ull << lane) - 1ull;
+            for (uint32_t j = 0; j < maxlen; ++j) {
+                const uint64_t mk = __builtin_amdgcn_ballot_w64(p <= j) & below;
+                const bool has = mk != 0ull;
+                const int k = has ? 63 - __builtin_clzll(mk) : 0;
+                const uint32_t sb = (uint32_t)__shfl((int)srcbase, k);
+                const uint8_t *from = has ? SUF + (uint32_t)(sb + j) : data + prev_off + j;
+                if (j < vlen) data[o0 + j] = *from;
+            }
+        } else {
+            const uint32_t nlive = min((uint32_t)kWave, done - base);
+            for (uint32_t l = 0; l < nlive; ++l) {
+                const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)l);
+                const uint32_t vl = (uint32_t)__builtin_amdgcn_readlane((int)vlen, (int)l);
+                const uint32_t ol = (uint32_t)__builtin_amdgcn_readlane((int)o0, (int)l);
+                const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)soff, (int)l);
+                const uint32_t before = l ? (uint32_t)__builtin_amdgcn_readlane((int)o0, (int)(l - 1u)) : prev_off;
+                if (pl > 0u) {
+                    workgroup_fence();  // the value in front has to be in memory
+                    for (uint32_t j = (uint32_t)lane; j < pl; j += kWave) data[ol + j] = data[before + j];
+                }
+                for (uint32_t j = (uint32_t)lane; j < vl - pl; j += kWave) data[ol + pl + j] = SUF[sl + j];
+            }
+        }
+        prev_off = (uint32_t)__builtin_amdgcn_readlane((int)o0, 63);
+        sc = wave_last_u32(sincl);
+        workgroup_fence();
+    }
+    return res;
+}
+
+// Either byte-array encoding, output areas taken from the page descriptor.
+__device__ __forceinline__ ByteArrayResult byte_array_wave(uint32_t kind, uint32_t *window, const uint8_t *S, int64_t len,
+                                                           uint32_t n, const pq_page_desc &d, uint8_t *values, int lane)
+{
+    uint32_t *area = reinterpret_cast<uint32_t *>(values + d.dict_off);
+    if (kind == PQ_KIND_DELTA_BA)
+        return delta_ba_wave(window, S, len, n, d.dict_len, area, values + d.dst_off, (uint64_t)d.dst_cap, lane);
+    return delta_length_ba_wave(window, S, len, n, d.dict_len, area, values + d.dst_off, lane);
+}
+
+}  // namespace pq

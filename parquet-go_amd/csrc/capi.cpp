@@ -71,7 +71,9 @@ int group_of(uint32_t kind)
     case PQ_KIND_LEVELS:
     case PQ_KIND_PLAIN:
     case PQ_KIND_BOOL_PLAIN:
-    case PQ_KIND_BOOL_RLE: return 0;
+    case PQ_KIND_BOOL_RLE:
+    case PQ_KIND_DELTA_LENGTH_BA:
+    case PQ_KIND_DELTA_BA: return 0;
     case PQ_KIND_DELTA32: return 1;
     case PQ_KIND_DELTA64: return 2;
     case PQ_KIND_PAGE_V1:
@@ -81,6 +83,14 @@ int group_of(uint32_t kind)
 }
 
 // Bytes per output value of a descriptor (0 = it writes no value output).
+// PQ_KIND_DELTA_LENGTH_BA / PQ_KIND_DELTA_BA when the descriptor (or its page's values) is one, else 0
+uint32_t byte_array_kind(const pq_page_desc &d)
+{
+    const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
+    const uint32_t k = page ? d.value_kind : d.kind;
+    return k == PQ_KIND_DELTA_LENGTH_BA || k == PQ_KIND_DELTA_BA ? k : 0u;
+}
+
 uint32_t value_size(const pq_page_desc &d)
 {
     uint32_t k = d.kind;
@@ -105,8 +115,13 @@ int validate(const pq_page_desc &d)
     const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
     if (page && d.value_kind != PQ_KIND_DICT && d.value_kind != PQ_KIND_DELTA32 &&
         d.value_kind != PQ_KIND_DELTA64 && d.value_kind != PQ_KIND_PLAIN && d.value_kind != PQ_KIND_BOOL_PLAIN &&
-        d.value_kind != PQ_KIND_BOOL_RLE)
+        d.value_kind != PQ_KIND_BOOL_RLE && d.value_kind != PQ_KIND_DELTA_LENGTH_BA &&
+        d.value_kind != PQ_KIND_DELTA_BA)
         return PQ_ERR_BAD_ARGUMENT;
+    if (byte_array_kind(d) != 0) {
+        if ((d.dict_off & 3u) || d.dict_len < d.n_values || d.dict_len > 0x3fffffffu || d.src_len > 0xffffffffull)
+            return PQ_ERR_BAD_ARGUMENT;
+    }
     const bool plain = d.kind == PQ_KIND_PLAIN || (page && d.value_kind == PQ_KIND_PLAIN);
     if (plain && d.elem_size != 4 && d.elem_size != 8) return PQ_ERR_BAD_ARGUMENT;
     const bool dict = d.kind == PQ_KIND_DICT || (page && d.value_kind == PQ_KIND_DICT);
@@ -163,6 +178,9 @@ const char *pq_status_string(int s)
     case PQ_NOT_INITIALIZED: return "reader is not initialized";
     case PQ_INVALID_STREAM: return "invalid stream";
     case PQ_PAGE_VALUES_FAILED: return "read values from page failed";
+    case PQ_BYTE_ARRAY_NEGATIVE_LEN: return "negative byte array length (the reference panics)";
+    case PQ_BYTE_ARRAY_COUNT_MISMATCH: return "bytearray/delta: different number of suffixes and prefixes";
+    case PQ_BYTE_ARRAY_INVALID_PREFIX: return "invalid prefix len in the stream";
     case PQ_ERR_BAD_ARGUMENT: return "bad argument";
     case PQ_ERR_HIP: return "HIP runtime error";
     case PQ_ERR_NO_DEVICE: return "no HIP device";
@@ -327,6 +345,12 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
         const uint32_t vs = value_size(d);
         if (vs) plan->values_need = std::max(plan->values_need, d.dst_off + (uint64_t)d.n_values * vs);
         const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
+        if (const uint32_t ba = byte_array_kind(d)) {
+            const bool front = ba == PQ_KIND_DELTA_BA;  // values rebuilt from prefixes: caller-sized
+            plan->values_need = std::max(plan->values_need, d.dst_off + (front ? (uint64_t)d.dst_cap : d.src_len));
+            plan->values_need = std::max(plan->values_need,
+                                         d.dict_off + (uint64_t)4 * ((uint64_t)(front ? 2 : 1) * d.dict_len + 1));
+        }
         if (page || d.kind == PQ_KIND_LEVELS)
             plan->levels_need = std::max(plan->levels_need, d.def_off + (uint64_t)4 * d.n_values);
         if (page) plan->levels_need = std::max(plan->levels_need, d.rep_off + (uint64_t)4 * d.n_values);
@@ -600,6 +624,79 @@ int pq_delta_decode64(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t 
                       uint32_t *n_decoded, uint64_t *consumed)
 {
     return delta_host(ctx, PQ_KIND_DELTA64, src, src_len, n, dst, 8, n_decoded, consumed);
+}
+
+// The value count an INT32 DELTA_BINARY_PACKED header at src declares, clamped to what a stream of
+// that size can possibly hold; *end = the offset behind the three header varints.
+static uint64_t declared_lengths(const uint8_t *src, size_t src_len, size_t *end)
+{
+    uint64_t v[3] = {0, 0, 0};
+    size_t pos = 0;
+    for (int k = 0; k < 3; ++k) {
+        int shift = 0;
+        while (pos < src_len && shift < 64) {
+            const uint8_t b = src[pos++];
+            v[k] |= (uint64_t)(b & 0x7f) << shift;
+            shift += 7;
+            if (!(b & 0x80)) break;
+        }
+    }
+    if (end) *end = pos;
+    return std::min<uint64_t>(v[2], 32ull * src_len + 256);
+}
+
+static int byte_array_host(pq_ctx *ctx, uint32_t kind, const uint8_t *src, size_t src_len, uint32_t n,
+                           uint32_t *offsets, uint8_t *data, size_t data_cap, uint32_t *n_decoded,
+                           uint64_t *consumed, int *init_failed)
+{
+    if (!ctx || !offsets || (src_len && !src) || (data_cap && !data) || n > 0x3fffffffu ||
+        src_len > 0xffffffffull || data_cap > 0xffffffffull)
+        return PQ_ERR_BAD_ARGUMENT;
+    // room for every length the stream declares.  The suffix lengths of a DELTA_BYTE_ARRAY stream
+    // start somewhere behind the prefix lengths: the two counts have to agree for Init to succeed,
+    // so the first count sizes both.
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(0x3fffffffull, std::max<uint64_t>(n, declared_lengths(src, src_len, nullptr)));
+    const bool front = kind == PQ_KIND_DELTA_BA;
+    pq_page_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.kind = kind;
+    d.n_values = n;
+    d.dst_off = 0;
+    d.dst_cap = front ? (uint32_t)data_cap : 0;
+    d.dict_off = (data_cap + 15) / 16 * 16;
+    d.dict_len = cap;
+    const size_t bytes = (size_t)d.dict_off + 4 * ((front ? 2 : 1) * (size_t)cap + 1);
+    std::vector<uint8_t> tmp(bytes);
+    pq_page_result r;
+    const int st = one_page(ctx, d, src, src_len, tmp.data(), bytes, nullptr, 0, nullptr, 0, &r);
+    if (st != PQ_OK) return st;
+    const bool init_bad = r.stage == PQ_STAGE_VALUES_INIT;
+    const uint32_t nd = init_bad ? 0 : r.n_decoded;
+    offsets[0] = 0;
+    if (!init_bad && r.status != PQ_ERR_OUT_OF_RANGE) {
+        std::memcpy(offsets, tmp.data() + d.dict_off, 4 * ((size_t)nd + 1));
+        if (offsets[nd]) std::memcpy(data, tmp.data(), offsets[nd]);
+    }
+    if (n_decoded) *n_decoded = nd;
+    if (consumed) *consumed = r.consumed;
+    if (init_failed) *init_failed = init_bad ? 1 : 0;
+    return r.status;
+}
+
+int pq_delta_length_ba_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n,
+                              uint32_t *offsets, uint8_t *data, uint32_t *n_decoded,
+                              uint64_t *consumed, int *init_failed)
+{
+    return byte_array_host(ctx, PQ_KIND_DELTA_LENGTH_BA, src, src_len, n, offsets, data, src_len, n_decoded, consumed,
+                           init_failed);
+}
+
+int pq_delta_ba_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n, uint32_t *offsets,
+                       uint8_t *data, size_t data_cap, uint32_t *n_decoded, uint64_t *consumed,
+                       int *init_failed)
+{
+    return byte_array_host(ctx, PQ_KIND_DELTA_BA, src, src_len, n, offsets, data, data_cap, n_decoded, consumed,
+                           init_failed);
 }
 
 // ---- level post-processing ----------------------------------------------------

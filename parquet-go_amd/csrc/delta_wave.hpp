@@ -27,6 +27,7 @@ constexpr int kDwBlockMax = 544;  // >= 10 + 4 + 512 (largest 128-value block), 
 constexpr int kDwStride = kDwChunk - kDwBlockMax; // distance between consecutive windows
 constexpr int kDwPieces = kDwChunk / 16 / kWave; // 16-byte pieces per lane
 constexpr int32_t kNeedGeneric = -2;
+constexpr int32_t kOverCap = -3;  // the stream declares more values than the caller's `cap`
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -339,16 +340,18 @@ struct WaveDeltaResult {
     uint32_t n_decoded;
     uint64_t consumed;
     uint32_t init_failed;
+    uint32_t total;  // the value count the stream header declares (0 when the header failed)
 };
 
-// Decode one page with one wave.  `lds` is this wave's private window.
+// Decode one page with one wave.  `lds` is this wave's private window.  A stream that
+// declares more than `cap` values is not decoded at all (status kOverCap).
 template <typename UT>
 __device__ __forceinline__ WaveDeltaResult delta_wave(uint32_t *lds, const uint8_t *S, int64_t len, uint32_t n,
-                                                      UT *dst, int lane)
+                                                      UT *dst, int lane, uint32_t cap = 0xffffffffu)
 {
     const uint8_t *B = reinterpret_cast<const uint8_t *>(lds);
     const bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & (2 * sizeof(UT) - 1)) == 0;
-    WaveDeltaResult res{PQ_OK, 0, 0, 0};
+    WaveDeltaResult res{PQ_OK, 0, 0, 0, 0};
     WavePrefetch pf;
 
     int64_t c0 = chunk_base(S, 0);
@@ -393,6 +396,11 @@ __device__ __forceinline__ WaveDeltaResult delta_wave(uint32_t *lds, const uint8
         return res;
     }
     const uint32_t total32 = uni((uint32_t)total);
+    res.total = total32;
+    if (total32 > cap) {
+        res.status = kOverCap;
+        return res;
+    }
     if (total32 == 0) { // every pull is io.EOF (:97-100)
         res.status = n > 0 ? PQ_EOF : PQ_OK;
         res.consumed = (uint64_t)pos;

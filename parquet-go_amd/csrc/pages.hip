@@ -13,6 +13,7 @@
 #include "delta_wave.hpp"
 #include "hybrid_stream.hpp"
 #include "hybrid_wave.hpp"
+#include "bytearray_wave.hpp"
 #include "pq_launch.hpp"
 
 namespace pq {
@@ -165,6 +166,22 @@ __device__ __forceinline__ HybridResult dict_values(HybridShared &sh, const uint
     return r;
 }
 
+// DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY in the workgroup-per-stream kernels: the first wave
+// does it alone, in the staging window of the hybrid decoder.
+__device__ __forceinline__ ByteArrayResult byte_array_wg(uint32_t kind, HybridShared &sh, const uint8_t *S, int64_t len,
+                                                         uint32_t n, const pq_page_desc &d, uint8_t *values)
+{
+    static_assert(sizeof(sh.chunk) >= (size_t)kDwChunk + 16, "window too small for delta_wave");
+    __shared__ ByteArrayResult slot;
+    __syncthreads();
+    if (threadIdx.x < (unsigned)kWave) {
+        const ByteArrayResult br = byte_array_wave(kind, sh.chunk, S, len, n, d, values, (int)threadIdx.x);
+        if (threadIdx.x == 0) slot = br;
+    }
+    __syncthreads();
+    return slot;
+}
+
 // ---------------------------------------------------------------------------
 
 __global__ __launch_bounds__(kWG) void stream_pages_kernel(const pq_page_desc *__restrict__ descs,
@@ -212,6 +229,12 @@ __global__ __launch_bounds__(kWG) void stream_pages_kernel(const pq_page_desc *_
                 r.consumed = (uint64_t)len;
             }
         }
+    } else if (d.kind == PQ_KIND_DELTA_LENGTH_BA || d.kind == PQ_KIND_DELTA_BA) {
+        const ByteArrayResult br = byte_array_wg(d.kind, sh, S, len, n, d, buf.values);
+        r.status = br.status;
+        r.n_decoded = br.n_decoded;
+        r.consumed = br.consumed;
+        extra = br.init_failed ? PQ_STAGE_VALUES_INIT : PQ_STAGE_NONE;
     } else if (d.kind == PQ_KIND_PLAIN) {
         r = plain_values_wg(S, len, n, d.elem_size, reinterpret_cast<uint32_t *>(buf.values + d.dst_off));
     } else if (d.kind == PQ_KIND_BOOL_PLAIN) {
@@ -233,11 +256,10 @@ __global__ __launch_bounds__(kWG) void stream_pages_kernel(const pq_page_desc *_
                                       &init_status);
         (void)init_status;
     }
-    (void)extra;
     if (threadIdx.x == 0) {
         pq_page_result out;
         out.status = r.status;
-        out.stage = PQ_STAGE_NONE;
+        out.stage = (int32_t)extra;
         out.detail = 0;
         out.n_decoded = r.n_decoded;
         out.not_null = r.count_max;
@@ -464,6 +486,11 @@ __device__ __forceinline__ void data_page_wg(PageShared &sh, uint32_t *ldict, co
                                        reinterpret_cast<const uint32_t *>(ldict), in_lds, d.dict_len, &v_init);
         v_status = vr.status;
         v_count = vr.n_decoded;
+    } else if (d.value_kind == PQ_KIND_DELTA_LENGTH_BA || d.value_kind == PQ_KIND_DELTA_BA) {
+        const ByteArrayResult br = byte_array_wg(d.value_kind, sh.hy, VS, vlen, nvals, d, buf.values);
+        if (br.init_failed) v_init = br.status;
+        v_status = br.status;
+        v_count = br.n_decoded;
     } else if (d.value_kind == PQ_KIND_BOOL_RLE) {
         // BooleanRLEDecoder: InitSize at read(), then n x Next (types/boolean.go:177-196)
         const Section sec = section_init_size(VS, vlen, 1u);
@@ -647,6 +674,7 @@ __global__ __launch_bounds__(kHwWG) void stream_wave_kernel(const pq_page_desc *
     const uint32_t n = d.n_values;
 
     HybridResult r{PQ_OK, 0, 0, 0};
+    int32_t stage = PQ_STAGE_NONE;  // DELTA_LENGTH_BA: tells a failed Init from a failed DecodeValues
     if (d.kind == PQ_KIND_HYBRID || d.kind == PQ_KIND_LEVELS || d.kind == PQ_KIND_BOOL_RLE) {
         // BOOL_RLE: NewHybridDecoder(1, false).InitSize (types/boolean.go:177-181)
         const bool levels = d.kind == PQ_KIND_LEVELS, brle = d.kind == PQ_KIND_BOOL_RLE;
@@ -671,6 +699,12 @@ __global__ __launch_bounds__(kHwWG) void stream_wave_kernel(const pq_page_desc *
             else if (levels && !sec.no_reader)
                 r.consumed = (uint64_t)len;
         }
+    } else if (d.kind == PQ_KIND_DELTA_LENGTH_BA || d.kind == PQ_KIND_DELTA_BA) {
+        const ByteArrayResult br = byte_array_wave(d.kind, L.window, S, len, n, d, buf.values, lane);
+        r.status = br.status;
+        r.n_decoded = br.n_decoded;
+        r.consumed = br.consumed;
+        stage = br.init_failed ? PQ_STAGE_VALUES_INIT : PQ_STAGE_NONE;
     } else if (d.kind == PQ_KIND_PLAIN) {
         r = plain_values_wave(L, S, len, n, d.elem_size, reinterpret_cast<uint32_t *>(buf.values + d.dst_off), lane);
     } else if (d.kind == PQ_KIND_BOOL_PLAIN) {
@@ -689,7 +723,7 @@ __global__ __launch_bounds__(kHwWG) void stream_wave_kernel(const pq_page_desc *
     if (lane == 0) {
         pq_page_result out;
         out.status = r.status;
-        out.stage = PQ_STAGE_NONE;
+        out.stage = stage;
         out.detail = 0;
         out.n_decoded = r.n_decoded;
         out.not_null = r.count_max;
@@ -824,6 +858,11 @@ __global__ __launch_bounds__(kHwWG) void data_wave_kernel(const pq_page_desc *__
                                             d.dict_len, &v_init, lane);
         v_status = vr.status;
         v_count = vr.n_decoded;
+    } else if (d.value_kind == PQ_KIND_DELTA_LENGTH_BA || d.value_kind == PQ_KIND_DELTA_BA) {
+        const ByteArrayResult br = byte_array_wave(d.value_kind, L.window, VS, vlen, nvals, d, buf.values, lane);
+        if (br.init_failed) v_init = br.status;
+        v_status = br.status;
+        v_count = br.n_decoded;
     } else if (d.value_kind == PQ_KIND_BOOL_RLE) {
         const Section sec = section_init_size(VS, vlen, 1u);
         v_init = sec.init_status;

@@ -251,3 +251,39 @@ def delta_encode(values, bits=64, block=128, miniblocks=4):
         idx = flat_off[sel][:, None] + np.arange(mbv * wv // 8)[None, :]
         out[idx.reshape(-1)] = packed.reshape(-1)
     return np.concatenate([head, out])
+
+
+# ---------------------------------------------------------------------------
+# DELTA_LENGTH_BYTE_ARRAY
+
+def delta_length_ba_encode(values, block=128, miniblocks=4):
+    """The reference ByteArrayDeltaLengthEncoder's stream (types/byte-array.go:120-164): the
+    lengths as an INT32 DELTA_BINARY_PACKED stream, then the values back to back."""
+    lens = np.array([len(v) for v in values], dtype=np.int32)
+    body = np.frombuffer(b"".join(bytes(v) for v in values), dtype=np.uint8)
+    return np.concatenate([delta_encode(lens, 32, block, miniblocks), body]).astype(np.uint8)
+
+
+def common_prefix_len(a, b):
+    """types/helpers.go:58-71: length of the longest common prefix."""
+    n = min(len(a), len(b))
+    if n == 0:
+        return 0
+    x = np.frombuffer(bytes(a[:n]), dtype=np.uint8) != np.frombuffer(bytes(b[:n]), dtype=np.uint8)
+    return int(np.argmax(x)) if x.any() else n
+
+
+def delta_ba_encode(values, block=128, miniblocks=4):
+    """The reference ByteArrayDeltaEncoder's stream (types/byte-array.go:225-275): the prefix lengths
+    against the value in front as an INT32 DELTA_BINARY_PACKED stream, then the suffixes as a
+    DELTA_LENGTH_BYTE_ARRAY stream."""
+    prev = b""
+    plens, suffixes = [], []
+    for v in values:
+        v = bytes(v)
+        k = common_prefix_len(prev, v)
+        plens.append(k)
+        suffixes.append(v[k:])
+        prev = v
+    return np.concatenate([delta_encode(np.array(plens, dtype=np.int32), 32, block, miniblocks),
+                           delta_length_ba_encode(suffixes, block, miniblocks)]).astype(np.uint8)

@@ -25,6 +25,13 @@ class Case:
         self.dictionary = kw.get("dictionary", None)
         self.plain_dtype = np.dtype(kw["plain_dtype"]) if "plain_dtype" in kw else None  # PLAIN values
         self.src_len = kw.get("src_len", None)  # override (e.g. truncate without copying)
+        # byte-array kinds: lengths the offsets area has room for, bytes of room for the values
+        self.offs_cap = kw.get("offs_cap", self.n)
+        self.data_cap = kw.get("data_cap", None)
+
+    def byte_array_kind(self):
+        k = self.value_kind if self.kind in (capi.KIND_PAGE_V1, capi.KIND_PAGE_V2) else self.kind
+        return k if k in (capi.KIND_DELTA_LENGTH_BA, capi.KIND_DELTA_BA) else 0
 
     def elem_size(self):
         k = self.value_kind if self.kind in (capi.KIND_PAGE_V1, capi.KIND_PAGE_V2) else self.kind
@@ -76,6 +83,18 @@ def run_cases(ctx, cases, seed=0):
             d["dst_off"] = val_pos
             c.val_off = val_pos
             val_pos += es * c.n + 8
+        if c.byte_array_kind():
+            front = c.byte_array_kind() == capi.KIND_DELTA_BA
+            c.room = int(c.data_cap) if front else int(d["src_len"])
+            val_pos += int(rng.integers(0, 9))
+            d["dst_off"] = c.val_off = val_pos
+            d["dst_cap"] = c.room if front else 0
+            val_pos += c.room + 8
+            val_pos = (val_pos + 3) // 4 * 4 + 4 * int(rng.integers(0, 4))
+            d["dict_off"] = c.area_off = val_pos
+            d["dict_len"] = c.offs_cap
+            c.area_words = (2 if front else 1) * c.offs_cap + 1
+            val_pos += 4 * c.area_words + 8
         if c.kind in (capi.KIND_LEVELS, capi.KIND_PAGE_V1, capi.KIND_PAGE_V2):
             lvl_pos += 4 * int(rng.integers(0, 5))
             d["def_off"] = lvl_pos
@@ -108,6 +127,11 @@ def run_cases(ctx, cases, seed=0):
         if es:
             c.values = values[c.val_off: c.val_off + es * c.n].view(c.value_dtype())
             c.guard = values[c.val_off + es * c.n: c.val_off + es * c.n + 8]
+        if c.byte_array_kind():
+            c.ba_data = values[c.val_off: c.val_off + c.room]
+            c.guard = values[c.val_off + c.room: c.val_off + c.room + 8]
+            c.ba_offsets = values[c.area_off: c.area_off + 4 * (c.offs_cap + 1)].view(np.uint32)
+            c.area_guard = values[c.area_off + 4 * c.area_words: c.area_off + 4 * c.area_words + 8]
         if c.kind in (capi.KIND_LEVELS, capi.KIND_PAGE_V1, capi.KIND_PAGE_V2):
             c.def_levels = levels[c.def_off // 4: c.def_off // 4 + c.n]
             c.def_guard = levels[c.def_off // 4 + c.n]

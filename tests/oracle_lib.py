@@ -19,6 +19,8 @@ INVALID_MINIBLOCK_WIDTH, DICT_INVALID_WIDTH, DICT_INVALID_INDEX, NOT_INITIALIZED
 INVALID_STREAM, PAGE_VALUES_FAILED = 14, 15
 
 VALUES_DICT, VALUES_DELTA32, VALUES_DELTA64, VALUES_PLAIN, VALUES_BOOL_PLAIN, VALUES_BOOL_RLE = 1, 2, 3, 4, 5, 6
+VALUES_DELTA_LENGTH_BA, VALUES_DELTA_BA = 7, 8
+BYTE_ARRAY_NEGATIVE_LEN, BYTE_ARRAY_COUNT_MISMATCH, BYTE_ARRAY_INVALID_PREFIX, OUT_OF_RANGE_CAP = 16, 17, 18, 103
 
 
 def build():
@@ -35,7 +37,8 @@ class PageIn(C.Structure):
     _fields_ = [("src", C.c_void_p), ("src_len", C.c_uint64), ("version", C.c_uint32),
                 ("num_values", C.c_uint32), ("max_rep", C.c_uint32), ("max_def", C.c_uint32),
                 ("rep_len", C.c_uint32), ("def_len", C.c_uint32), ("value_kind", C.c_uint32),
-                ("elem_size", C.c_uint32), ("dict", C.c_void_p), ("dict_len", C.c_uint32)]
+                ("elem_size", C.c_uint32), ("dict", C.c_void_p), ("dict_len", C.c_uint32),
+                ("data_cap", C.c_uint64)]
 
 
 class PageOut(C.Structure):
@@ -188,6 +191,30 @@ def bool_plain_decode(src, n):
     return dict(status=st, values=out[:nd.value].copy(), n_decoded=nd.value, consumed=cons.value)
 
 
+def delta_length_ba_decode(src, n):
+    """-> dict(status, init_status, n_decoded, consumed, values_count, offsets[:n_decoded + 1], data)"""
+    s = _u8(src)
+    offsets = np.zeros(n + 1, dtype=np.uint32)
+    data = np.zeros(s.size + 1, dtype=np.uint8)
+    nd, cons, vc, init = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0), C.c_int(0)
+    st = lib().pqo_delta_length_ba_decode(_ptr(s), C.c_size_t(s.size), C.c_uint32(n), _ptr(offsets), _ptr(data),
+                                          C.byref(nd), C.byref(cons), C.byref(vc), C.byref(init))
+    return dict(status=st, init_status=init.value, n_decoded=nd.value, consumed=cons.value, values_count=vc.value,
+                offsets=offsets[:nd.value + 1].copy(), data=data[:int(offsets[nd.value])].copy())
+
+
+def delta_ba_decode(src, n, data_cap):
+    """-> the dictionary of delta_length_ba_decode, for ByteArrayDeltaDecoder with data_cap bytes of room"""
+    s = _u8(src)
+    offsets = np.zeros(n + 1, dtype=np.uint32)
+    data = np.zeros(int(data_cap) + 1, dtype=np.uint8)
+    nd, cons, vc, init = C.c_uint32(0), C.c_uint64(0), C.c_uint32(0), C.c_int(0)
+    st = lib().pqo_delta_ba_decode(_ptr(s), C.c_size_t(s.size), C.c_uint32(n), _ptr(offsets), _ptr(data),
+                                   C.c_uint64(int(data_cap)), C.byref(nd), C.byref(cons), C.byref(vc), C.byref(init))
+    return dict(status=st, init_status=init.value, n_decoded=nd.value, consumed=cons.value, values_count=vc.value,
+                offsets=offsets[:nd.value + 1].copy(), data=data[:int(offsets[nd.value])].copy())
+
+
 def levels_pack(levels, w):
     """PackedArray bytes of AppendSingle x n and, for n > 0, Flush."""
     lv = np.ascontiguousarray(levels, dtype=np.int32)
@@ -247,8 +274,9 @@ def delta_encode64(values, block=128, miniblocks=4):
 
 
 def page_read(src, version, num_values, max_rep, max_def, value_kind, dictionary=None,
-              rep_len=0, def_len=0, value_dtype=None):
-    """-> dict(status, stage, detail, n, not_null, values_decoded, rep, def_, values)"""
+              rep_len=0, def_len=0, value_dtype=None, data_cap=0):
+    """-> dict(status, stage, detail, n, not_null, values_decoded, rep, def_, values).  Byte-array value kinds:
+    values = (num_values + 1) uint32 offsets followed by the value bytes (data_cap of them for DELTA_BA)."""
     s = _u8(src)
     pin = PageIn()
     pin.src = s.ctypes.data if s.size else None
@@ -270,6 +298,9 @@ def page_read(src, version, num_values, max_rep, max_def, value_kind, dictionary
         pin.elem_size = vdt.itemsize
     elif value_kind in (VALUES_BOOL_PLAIN, VALUES_BOOL_RLE):
         vdt = np.dtype(np.int32)
+    elif value_kind in (VALUES_DELTA_LENGTH_BA, VALUES_DELTA_BA):
+        vdt = np.dtype(np.uint8)
+        pin.data_cap = int(data_cap)
     else:
         vdt = np.dtype(np.int32 if value_kind == VALUES_DELTA32 else np.int64)
     if value_dtype is not None:
@@ -277,8 +308,11 @@ def page_read(src, version, num_values, max_rep, max_def, value_kind, dictionary
     rep = np.zeros(max(num_values, 1), dtype=np.int32)
     deff = np.zeros(max(num_values, 1), dtype=np.int32)
     vals = np.zeros(max(num_values, 1), dtype=vdt)
+    if value_kind in (VALUES_DELTA_LENGTH_BA, VALUES_DELTA_BA):   # (num_values + 1) uint32 offsets, then the bytes
+        room = s.size if value_kind == VALUES_DELTA_LENGTH_BA else int(data_cap)
+        vals = np.zeros(4 * (num_values + 1) + room + 8, dtype=np.uint8)
     po = PageOut()
     lib().pqo_page_read(C.byref(pin), _ptr(rep), _ptr(deff), _ptr(vals), C.byref(po))
     return dict(status=po.status, stage=po.stage, detail=po.detail, n=po.n, not_null=po.not_null,
                 values_decoded=po.values_decoded, rep=rep[:num_values], def_=deff[:num_values],
-                values=vals[:num_values])
+                values=vals if value_kind in (VALUES_DELTA_LENGTH_BA, VALUES_DELTA_BA) else vals[:num_values])
