@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 /* ---- status codes ---------------------------------------------------------
- * 1..18 are the reference's error classes; >= 100 are the library's own. */
+ * 1..30 are the reference's error classes; >= 100 are the library's own. */
 #define PQ_OK 0
 #define PQ_EOF 1                     /* io.EOF */
 #define PQ_UNEXPECTED_EOF 2          /* io.ErrUnexpectedEOF */
@@ -49,6 +49,20 @@ extern "C" {
 #define PQ_BYTE_ARRAY_NEGATIVE_LEN 16/* types/byte-array.go:210,326: make([]byte, ..) panics for a size < 0 */
 #define PQ_BYTE_ARRAY_COUNT_MISMATCH 17 /* types/byte-array.go:303: different number of suffixes and prefixes */
 #define PQ_BYTE_ARRAY_INVALID_PREFIX 18 /* types/byte-array.go:331: invalid prefix len in the stream */
+/* page-header walk (pq_walk_chunks) */
+#define PQ_WALK_HEADER_FAILED 19          /* layout/chunk.go:142: failed to read page header */
+#define PQ_WALK_SECOND_DICTIONARY 20      /* layout/chunk.go:150: there should be only one dictionary */
+#define PQ_WALK_PAGE_TYPE 21              /* layout/chunk.go:189: page type not supported */
+#define PQ_WALK_MISSING_HEADER 22         /* layout/page-v1.go:42 (in fact the nil dereference of :22),
+                                             page-v2.go:46, page-dict.go:30 */
+#define PQ_WALK_NEGATIVE_NUM_VALUES 23    /* layout/page-v1.go:45, page-v2.go:49, page-dict.go:33 */
+#define PQ_WALK_NEGATIVE_LEVELS_LENGTH 24 /* layout/page-v2.go:57-71 */
+#define PQ_WALK_DICT_ENCODING 25          /* layout/page-dict.go:42 */
+#define PQ_WALK_LEVEL_ENCODING 26         /* layout/chunk.go:79,95 */
+#define PQ_WALK_VALUE_ENCODING 27         /* layout/page-dict.go:84-345: no decoder for this type / encoding */
+#define PQ_WALK_BLOCK_SIZE 28             /* layout/block.go:23, page-v2.go:87-90: the page's bytes are not there */
+#define PQ_WALK_UNCOMPRESSED_SIZE 29      /* layout/block.go:37 */
+#define PQ_WALK_SEEK 30                   /* layout/chunk.go:174 */
 
 #define PQ_ERR_BAD_ARGUMENT 100
 #define PQ_ERR_HIP 101               /* a HIP runtime call failed; see pq_last_error */
@@ -251,6 +265,85 @@ int pq_delta_length_ba_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, u
 int pq_delta_ba_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n,
                        uint32_t *offsets, uint8_t *data, size_t data_cap, uint32_t *n_decoded,
                        uint64_t *consumed, int *init_failed);
+
+/* ---- Page-header walk: ChunkReader.readPages (layout/chunk.go:129-217) -------------------
+ *
+ * Replaces, for every column chunk of a row group at once, the loop that reads one Thrift
+ * compact PageHeader after the other (readThrift, layout/helpers.go:16-23; PageHeader.Read,
+ * parquet/parquet.go:5886), applies the header checks of the page readers' read()
+ * (layout/page-v1.go:40-67, page-v2.go:42-108, page-dict.go:28-57) and steps over the page block
+ * (readBlockData, layout/block.go:17-47).  The chunk bytes are in device memory; the result is
+ * one pq_page_info per page, from which pq_chunk_page_descs builds the descriptors of the data
+ * pages.  Decompression stays with the caller's codec: for codec != 0 the walk reports where
+ * each block lies and how large it is on either side. */
+typedef struct pq_chunk_desc {
+    uint64_t src_off;              /* offset in the source buffer of the chunk's first page header: the
+                                      byte at file offset dictionary_page_offset when present, else
+                                      data_page_offset (layout/chunk.go:58-61) */
+    uint64_t src_len;              /* bytes the source holds from there on (to the end of the file) */
+    int64_t total_compressed_size; /* ColumnMetaData.TotalCompressedSize */
+    int64_t data_page_offset;      /* ColumnMetaData.DataPageOffset */
+    int64_t dictionary_page_offset;
+    uint32_t has_dictionary_page_offset;
+    uint32_t physical_type;        /* parquet.Type: 0 BOOLEAN 1 INT32 2 INT64 3 INT96 4 FLOAT 5 DOUBLE
+                                      6 BYTE_ARRAY 7 FIXED_LEN_BYTE_ARRAY */
+    int32_t type_length;           /* SchemaElement.TypeLength, < 0 when nil */
+    uint32_t max_rep;
+    uint32_t max_def;
+    uint32_t codec;                /* parquet.CompressionCodec; 0 = UNCOMPRESSED */
+    uint32_t info_first;           /* index of this chunk's first record in the info table */
+    uint32_t info_cap;             /* records it may write */
+} pq_chunk_desc;
+
+typedef struct pq_page_info {
+    int32_t type;              /* parquet.PageType: 0 DATA_PAGE, 2 DICTIONARY_PAGE, 3 DATA_PAGE_V2 */
+    int32_t encoding;          /* parquet.Encoding of the values */
+    int32_t num_values;
+    int32_t compressed_size;   /* PageHeader.CompressedPageSize */
+    int32_t uncompressed_size; /* PageHeader.UncompressedPageSize */
+    int32_t def_len;           /* V2: DefinitionLevelsByteLength */
+    int32_t rep_len;           /* V2: RepetitionLevelsByteLength */
+    int32_t def_encoding;      /* V1 */
+    int32_t rep_encoding;      /* V1 */
+    uint32_t is_compressed;    /* V2 (true when absent) */
+    uint64_t header_off;       /* offset from the chunk's src_off of the header's first byte */
+    uint64_t data_off;         /* ... of the first byte behind the header */
+} pq_page_info;
+
+typedef struct pq_chunk_result {
+    int32_t status;   /* PQ_OK, a PQ_WALK_* class, or PQ_ERR_OUT_OF_RANGE (more pages than info_cap) */
+    uint32_t n_pages; /* records written (the pages in front of the failing one) */
+    int64_t count;    /* offsetReader.Count() when the loop ended (layout/helpers.go:38-64) */
+} pq_chunk_result;
+
+/* d_src: device memory.  d_infos: device memory for the info table.  results: host memory, one
+ * per chunk; the call waits for the stream. */
+int pq_walk_chunks_dev(pq_ctx *ctx, const void *d_src, size_t src_bytes, const pq_chunk_desc *chunks,
+                       size_t n_chunks, pq_page_info *d_infos, size_t infos_cap,
+                       pq_chunk_result *results);
+/* Same from host memory; infos: host memory for infos_cap records. */
+int pq_walk_chunks(pq_ctx *ctx, const void *src, size_t src_bytes, const pq_chunk_desc *chunks,
+                   size_t n_chunks, pq_page_info *infos, size_t infos_cap, pq_chunk_result *results);
+
+/* Where the outputs of a walked chunk go (all offsets in bytes, all advanced by the call). */
+typedef struct pq_chunk_layout {
+    uint64_t values_off;  /* values buffer */
+    uint64_t levels_off;  /* levels buffer */
+    uint64_t dict_off;    /* dictionary buffer: the chunk's dictionary is expected at the 8-byte aligned
+                             offset the call reports in *dict_dst, copied from src[*dict_src ..) */
+    uint32_t delta_ba_room; /* DELTA_BYTE_ARRAY pages: bytes of room per page for the rebuilt values */
+} pq_chunk_layout;
+
+/* Host-side bookkeeping, no device work: descriptors (PQ_KIND_PAGE_V1 / _V2) for the data pages
+ * of an UNCOMPRESSED chunk, in page order, as getValuesDecoder pairs decoders with encodings
+ * (layout/page-dict.go:143-345).  descs: room for n_pages.  *dict_src / *dict_dst / *dict_bytes:
+ * the PLAIN fixed-width dictionary body the caller copies (device to device) before running the
+ * plan; *dict_bytes == 0 when the chunk has none.  Returns PQ_ERR_BAD_ARGUMENT for a compressed
+ * chunk and for types whose values this library does not decode (INT96, FIXED_LEN_BYTE_ARRAY,
+ * PLAIN byte arrays, byte-array and boolean dictionaries). */
+int pq_chunk_page_descs(const pq_chunk_desc *chunk, const pq_page_info *infos, uint32_t n_pages,
+                        pq_chunk_layout *layout, pq_page_desc *descs, uint32_t *n_descs,
+                        uint64_t *dict_src, uint64_t *dict_dst, uint64_t *dict_bytes);
 
 /* ---- Level post-processing: what the reference does with decoded levels, value by value ----
  *

@@ -1114,6 +1114,321 @@ void pqo_page_read(const pqo_page_in *in, int32_t *rep, int32_t *def, void *valu
 }
 
 /* ------------------------------------------------------------------------- */
+/* Thrift compact protocol, as much of it as PageHeader.Read needs               */
+
+enum { T_STOP = 0, T_BOOL_TRUE = 1, T_BOOL_FALSE = 2, T_BYTE = 3, T_I16 = 4, T_I32 = 5, T_I64 = 6,
+       T_DOUBLE = 7, T_BINARY = 8, T_LIST = 9, T_SET = 10, T_MAP = 11, T_STRUCT = 12 };
+
+/* readVarint64: bytes until one without the continuation bit; bits beyond 64 fall off. */
+static int th_varint(rd_t *r, uint64_t *out)
+{
+    uint64_t v = 0;
+    unsigned shift = 0;
+    for (;;) {
+        uint8_t b;
+        if (rd_byte(r, &b) != PQO_OK) return PQO_EOF;
+        if (shift < 64) v |= (uint64_t)(b & 0x7f) << shift;
+        if (!(b & 0x80)) break;
+        shift += 7;
+    }
+    *out = v;
+    return PQO_OK;
+}
+
+static int th_i32(rd_t *r, int32_t *out) /* ReadI32: int32(varint), zig-zag */
+{
+    uint64_t u;
+    if (th_varint(r, &u) != PQO_OK) return PQO_EOF;
+    uint32_t x = (uint32_t)u;
+    *out = (int32_t)((x >> 1) ^ (uint32_t)-(int32_t)(x & 1));
+    return PQO_OK;
+}
+
+/* ReadFieldBegin: type 0 in the low nibble is STOP whatever the high nibble says. */
+static int th_field(rd_t *r, int *type, int32_t *id, int32_t *last_id)
+{
+    uint8_t b;
+    if (rd_byte(r, &b) != PQO_OK) return PQO_EOF;
+    *type = b & 0x0f;
+    if (*type == T_STOP) return PQO_OK;
+    if (*type > T_STRUCT) return PQO_INVALID_STREAM;
+    int delta = b >> 4;
+    if (delta == 0) {
+        int32_t v;
+        if (th_i32(r, &v) != PQO_OK) return PQO_EOF;
+        *id = (int16_t)v;
+    } else {
+        *id = (int16_t)(*last_id + delta);
+    }
+    *last_id = *id;
+    return PQO_OK;
+}
+
+static int th_skip(rd_t *r, int type, int depth, int in_collection)
+{
+    uint64_t u;
+    if (depth <= 0) return PQO_INVALID_STREAM; /* "Depth limit exceeded" */
+    switch (type) {
+    case T_BOOL_TRUE:
+    case T_BOOL_FALSE: /* a field's boolean lives in its type nibble; in a collection it is a byte */
+        return in_collection ? rd_read_full(r, NULL, 1) : PQO_OK;
+    case T_BYTE: return rd_read_full(r, NULL, 1);
+    case T_I16:
+    case T_I32:
+    case T_I64: return th_varint(r, &u);
+    case T_DOUBLE: return rd_read_full(r, NULL, 8) == PQO_OK ? PQO_OK : PQO_EOF;
+    case T_BINARY: {
+        if (th_varint(r, &u) != PQO_OK) return PQO_EOF;
+        int32_t n = (int32_t)(uint32_t)u;
+        if (n < 0) return PQO_INVALID_STREAM;
+        if (n == 0) return PQO_OK;
+        return rd_read_full(r, NULL, (size_t)n) == PQO_OK ? PQO_OK : PQO_EOF;
+    }
+    case T_STRUCT: {
+        int32_t last = 0, id = 0;
+        for (;;) {
+            int t;
+            int st = th_field(r, &t, &id, &last);
+            if (st != PQO_OK) return st;
+            if (t == T_STOP) return PQO_OK;
+            st = th_skip(r, t, depth - 1, 0);
+            if (st != PQO_OK) return st;
+        }
+    }
+    case T_LIST:
+    case T_SET: {
+        uint8_t b;
+        if (rd_byte(r, &b) != PQO_OK) return PQO_EOF;
+        int32_t n = b >> 4;
+        int et = b & 0x0f;
+        if (n == 15) {
+            if (th_varint(r, &u) != PQO_OK) return PQO_EOF;
+            n = (int32_t)(uint32_t)u;
+            if (n < 0) return PQO_INVALID_STREAM;
+        }
+        if (et > T_STRUCT) return PQO_INVALID_STREAM;
+        for (int32_t i = 0; i < n; i++) {
+            int st = th_skip(r, et, depth - 1, 1);
+            if (st != PQO_OK) return st;
+        }
+        return PQO_OK;
+    }
+    case T_MAP: {
+        if (th_varint(r, &u) != PQO_OK) return PQO_EOF;
+        int32_t n = (int32_t)(uint32_t)u;
+        if (n < 0) return PQO_INVALID_STREAM;
+        uint8_t kv = 0;
+        if (n != 0 && rd_byte(r, &kv) != PQO_OK) return PQO_EOF;
+        int kt = kv >> 4, vt = kv & 0x0f;
+        if (kt > T_STRUCT || vt > T_STRUCT) return PQO_INVALID_STREAM;
+        for (int32_t i = 0; i < n; i++) {
+            int st = th_skip(r, kt, depth - 1, 1);
+            if (st == PQO_OK) st = th_skip(r, vt, depth - 1, 1);
+            if (st != PQO_OK) return st;
+        }
+        return PQO_OK;
+    }
+    default: return PQO_OK; /* STOP: nothing to skip */
+    }
+}
+
+typedef struct {
+    int present;
+    int32_t f[8];     /* captured i32 fields, by field id */
+    uint32_t isset;   /* bit id: field seen with the expected type */
+    uint32_t is_compressed;
+} th_sub_t;
+
+/* One of DataPageHeader / IndexPageHeader / DictionaryPageHeader / DataPageHeaderV2
+ * (parquet/parquet.go:3994, :4252, :4334, :4586): i32_mask = ids read as i32, required = ids that must
+ * be there, bool_id = the boolean field (0: none). */
+static int th_sub(rd_t *r, th_sub_t *h, uint32_t i32_mask, uint32_t required, int bool_id)
+{
+    memset(h, 0, sizeof *h);
+    h->present = 1;
+    h->is_compressed = 1; /* NewDataPageHeaderV2 */
+    int32_t last = 0, id = 0;
+    for (;;) {
+        int t;
+        int st = th_field(r, &t, &id, &last);
+        if (st != PQO_OK) return st;
+        if (t == T_STOP) break;
+        if (id >= 1 && id < 8 && ((i32_mask >> id) & 1) && t == T_I32) {
+            if (th_i32(r, &h->f[id]) != PQO_OK) return PQO_EOF;
+            h->isset |= 1u << id;
+        } else if (id == bool_id && (t == T_BOOL_TRUE || t == T_BOOL_FALSE)) {
+            h->is_compressed = t == T_BOOL_TRUE;
+        } else {
+            st = th_skip(r, t, 64, 0);
+            if (st != PQO_OK) return st;
+        }
+    }
+    return (h->isset & required) == required ? PQO_OK : PQO_INVALID_STREAM;
+}
+
+typedef struct {
+    int32_t type, uncompressed, compressed;
+    th_sub_t data, dict, v2;
+} th_page_header_t;
+
+/* PageHeader.Read (parquet/parquet.go:5886-6009) */
+static int th_page_header(rd_t *r, th_page_header_t *h)
+{
+    memset(h, 0, sizeof *h);
+    uint32_t isset = 0;
+    int32_t last = 0, id = 0;
+    for (;;) {
+        int t;
+        int st = th_field(r, &t, &id, &last);
+        if (st != PQO_OK) return st;
+        if (t == T_STOP) break;
+        if (id >= 1 && id <= 4 && t == T_I32) {
+            int32_t v;
+            if (th_i32(r, &v) != PQO_OK) return PQO_EOF;
+            if (id == 1) h->type = v;
+            if (id == 2) h->uncompressed = v;
+            if (id == 3) h->compressed = v;
+            isset |= 1u << id;
+        } else if (id == 5 && t == T_STRUCT) {
+            st = th_sub(r, &h->data, 0x1e, 0x1e, 0);
+        } else if (id == 6 && t == T_STRUCT) {
+            th_sub_t idx;
+            st = th_sub(r, &idx, 0, 0, 0);
+        } else if (id == 7 && t == T_STRUCT) {
+            st = th_sub(r, &h->dict, 0x06, 0x06, 0);
+        } else if (id == 8 && t == T_STRUCT) {
+            st = th_sub(r, &h->v2, 0x7e, 0x7e, 7);
+        } else {
+            st = th_skip(r, t, 64, 0);
+        }
+        if (st != PQO_OK) return st;
+    }
+    return (isset & 0x0e) == 0x0e ? PQO_OK : PQO_INVALID_STREAM;
+}
+
+/* getValuesDecoder (layout/page-dict.go:143-345): does the reference have a decoder for this
+ * encoding of this type? */
+static int values_decoder_exists(uint32_t type, int32_t type_length, int32_t enc)
+{
+    if (enc == 2) enc = 8; /* PLAIN_DICTIONARY -> RLE_DICTIONARY */
+    switch (type) {
+    case 0: return enc == 0 || enc == 3 || enc == 8;
+    case 1:
+    case 2: return enc == 0 || enc == 5 || enc == 8;
+    case 3:
+    case 4:
+    case 5: return enc == 0 || enc == 8;
+    case 6: return enc == 0 || enc == 6 || enc == 7 || enc == 8;
+    case 7: return type_length >= 0 && (enc == 0 || enc == 7 || enc == 8);
+    default: return 0;
+    }
+}
+
+/* readBlockData (layout/block.go:17-47) for `compressed` bytes at the reader. */
+static int walk_block(rd_t *r, uint32_t codec, int32_t compressed, int32_t uncompressed)
+{
+    size_t left = r->len - r->pos;
+    size_t want = compressed > 0 ? (size_t)compressed : 0; /* io.LimitReader of a negative size reads nothing */
+    size_t got = want < left ? want : left;
+    r->pos += got;
+    if ((int64_t)got != (int64_t)compressed) return PQO_WALK_BLOCK_SIZE;
+    if (codec == 0 && compressed != uncompressed) return PQO_WALK_UNCOMPRESSED_SIZE;
+    return PQO_OK;
+}
+
+int pqo_walk_chunk(const pqo_chunk_in *in, pqo_page_info *infos, uint32_t cap, uint32_t *n_pages,
+                   int64_t *count_out)
+{
+    rd_t r = {in->src, in->src_len, 0};
+    const int64_t start = in->has_dictionary_page_offset ? in->dictionary_page_offset : in->data_page_offset;
+    int64_t count = 0; /* offsetReader.count: bytes read plus seek distances */
+    uint32_t n = 0;
+    int have_dict = 0, st = PQO_OK;
+    for (;;) {
+        if (in->total_compressed_size - count < 1) break; /* chunk.go:136 */
+        size_t h0 = r.pos;
+        th_page_header_t h;
+        if (th_page_header(&r, &h) != PQO_OK) { st = PQO_WALK_HEADER_FAILED; count += (int64_t)(r.pos - h0); break; }
+        if (n >= cap) { st = PQO_OUT_OF_RANGE_CAP; break; }
+        pqo_page_info *pi = &infos[n];
+        memset(pi, 0, sizeof *pi);
+        pi->type = h.type;
+        pi->compressed_size = h.compressed;
+        pi->uncompressed_size = h.uncompressed;
+        pi->header_off = h0;
+        pi->data_off = r.pos;
+        pi->is_compressed = 1;
+        if (h.type == 2) { /* DICTIONARY_PAGE, chunk.go:148-180 + page-dict.go:28-57 */
+            if (have_dict) st = PQO_WALK_SECOND_DICTIONARY;
+            else if (in->physical_type == 0 || in->physical_type > 7 ||
+                     (in->physical_type == 7 && in->type_length < 0)) st = PQO_WALK_VALUE_ENCODING;
+            else if (!h.dict.present) st = PQO_WALK_MISSING_HEADER;
+            else if (h.dict.f[1] < 0) st = PQO_WALK_NEGATIVE_NUM_VALUES;
+            else if (h.dict.f[2] != 0 && h.dict.f[2] != 2) st = PQO_WALK_DICT_ENCODING;
+            if (h.dict.present) { pi->num_values = h.dict.f[1]; pi->encoding = h.dict.f[2]; }
+            if (st == PQO_OK) st = walk_block(&r, in->codec, h.compressed, h.uncompressed);
+            count += (int64_t)(r.pos - h0);
+            if (st != PQO_OK) break;
+            have_dict = 1;
+            n++;
+            if (in->has_dictionary_page_offset && in->dictionary_page_offset != start + (int64_t)r.pos) {
+                /* Seek(DataPageOffset): count moves by the distance (layout/helpers.go:52-60) */
+                int64_t target = in->data_page_offset - start;
+                if (target < 0) { st = PQO_WALK_SEEK; break; }
+                count += target - (int64_t)r.pos;
+                r.pos = (uint64_t)target > r.len ? r.len : (size_t)target;
+            }
+            continue;
+        }
+        if (h.type == 0) { /* DATA_PAGE: init (page-v1.go:21-38) then read (:40-67) */
+            if (!h.data.present) st = PQO_WALK_MISSING_HEADER;
+            else if (in->max_rep != 0 && (h.data.f[3] != 3 || h.data.f[4] != 3)) st = PQO_WALK_LEVEL_ENCODING;
+            else if (h.data.f[1] < 0) st = PQO_WALK_NEGATIVE_NUM_VALUES;
+            if (h.data.present) {
+                pi->num_values = h.data.f[1];
+                pi->encoding = h.data.f[2];
+                pi->def_encoding = h.data.f[3];
+                pi->rep_encoding = h.data.f[4];
+            }
+            if (st == PQO_OK) st = walk_block(&r, in->codec, h.compressed, h.uncompressed);
+            if (st == PQO_OK && !values_decoder_exists(in->physical_type, in->type_length, h.data.f[2]))
+                st = PQO_WALK_VALUE_ENCODING;
+        } else if (h.type == 3) { /* DATA_PAGE_V2: page-v2.go:42-108 */
+            if (!h.v2.present) st = PQO_WALK_MISSING_HEADER;
+            else if (h.v2.f[1] < 0) st = PQO_WALK_NEGATIVE_NUM_VALUES;
+            else if (h.v2.f[6] < 0 || h.v2.f[5] < 0) st = PQO_WALK_NEGATIVE_LEVELS_LENGTH;
+            else if (!values_decoder_exists(in->physical_type, in->type_length, h.v2.f[4])) st = PQO_WALK_VALUE_ENCODING;
+            if (h.v2.present) {
+                pi->num_values = h.v2.f[1];
+                pi->encoding = h.v2.f[4];
+                pi->def_len = h.v2.f[5];
+                pi->rep_len = h.v2.f[6];
+                pi->is_compressed = h.v2.is_compressed;
+            }
+            if (st == PQO_OK) {
+                int32_t levels = (int32_t)((uint32_t)h.v2.f[5] + (uint32_t)h.v2.f[6]);
+                if (levels > 0) { /* io.ReadFull of both level sections */
+                    size_t left = r.len - r.pos;
+                    if (left < (size_t)levels) { r.pos = r.len; st = PQO_WALK_BLOCK_SIZE; }
+                    else r.pos += (size_t)levels;
+                }
+                if (st == PQO_OK)
+                    st = walk_block(&r, in->codec, (int32_t)((uint32_t)h.compressed - (uint32_t)levels),
+                                    (int32_t)((uint32_t)h.uncompressed - (uint32_t)levels));
+            }
+        } else {
+            st = PQO_WALK_PAGE_TYPE;
+        }
+        count += (int64_t)(r.pos - h0);
+        if (st != PQO_OK) break;
+        n++;
+    }
+    if (n_pages) *n_pages = n;
+    if (count_out) *count_out = count;
+    return st;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Encoders — input generators only.                                           */
 
 typedef struct {

@@ -186,6 +186,66 @@ void pqo_column_entries(const int32_t *def, const int32_t *rep, uint64_t n, int3
                         int32_t max_rep, int repeated, uint32_t *offsets, uint8_t *validity,
                         int32_t *entry_def, uint32_t *n_entries, uint32_t *n_values);
 
+/* ---- page-header walk of a column chunk: ChunkReader.readPages (layout/chunk.go:129-217) with the
+ *      header checks of the page readers' read() (layout/page-v1.go:40-67, layout/page-v2.go:42-108,
+ *      layout/page-dict.go:28-57) and layout/block.go:17-47 for the page block.  The Thrift compact
+ *      protocol reader is github.com/apache/thrift v0.0.0-20181112125854-24918abba929 (go.mod:10), a
+ *      dependency that is not vendored: restated from the published compact-protocol encoding
+ *      (field header = id delta << 4 | type, zig-zag varints, binary = varint length + bytes,
+ *      list/set header = size << 4 | type with 15 = varint size, map = varint size + type byte) and
+ *      from the generated readers in parquet/parquet.go (:3994, :4334, :4586, :5886).  How the library
+ *      treats malformed input beyond "an error" is unpinned; every header failure is one class here.
+ *      Nothing in the reference tests this loop: parity unpinned. ---- */
+enum pqo_walk_status {
+    PQO_WALK_HEADER_FAILED = 19,          /* "failed to read page header"                 chunk.go:142 */
+    PQO_WALK_SECOND_DICTIONARY = 20,      /* "there should be only one dictionary"        chunk.go:150 */
+    PQO_WALK_PAGE_TYPE = 21,              /* "page type not supported"                    chunk.go:189 */
+    PQO_WALK_MISSING_HEADER = 22,         /* "missing data page header" / dictionary      page-v1.go:42 (a nil
+                                             dereference in init, :22, comes first), page-v2.go:46, page-dict.go:30 */
+    PQO_WALK_NEGATIVE_NUM_VALUES = 23,    /* page-v1.go:45, page-v2.go:49, page-dict.go:33 */
+    PQO_WALK_NEGATIVE_LEVELS_LENGTH = 24, /* page-v2.go:57-71 */
+    PQO_WALK_DICT_ENCODING = 25,          /* page-dict.go:42 */
+    PQO_WALK_LEVEL_ENCODING = 26,         /* "encoding not supported for definition and repetition level" chunk.go:79,95 */
+    PQO_WALK_VALUE_ENCODING = 27,         /* getValuesDecoder / getDictValuesDecoder       page-dict.go:84-345 */
+    PQO_WALK_BLOCK_SIZE = 28,             /* "invalid size for compressed data" block.go:23; page-v2.go:87-90 */
+    PQO_WALK_UNCOMPRESSED_SIZE = 29,      /* "invalid size for decompressed data"         block.go:37 */
+    PQO_WALK_SEEK = 30                    /* "failed to set the read index ..."            chunk.go:174 */
+};
+
+typedef struct pqo_chunk_in {
+    const uint8_t *src;            /* the byte at file offset (dictionary_page_offset if present, else
+                                      data_page_offset) and everything the source holds behind it */
+    uint64_t src_len;
+    int64_t total_compressed_size; /* ColumnMetaData.TotalCompressedSize */
+    int64_t data_page_offset;
+    int64_t dictionary_page_offset;
+    uint32_t has_dictionary_page_offset;
+    uint32_t physical_type;        /* parquet.Type: 0 BOOLEAN 1 INT32 2 INT64 3 INT96 4 FLOAT 5 DOUBLE
+                                      6 BYTE_ARRAY 7 FIXED_LEN_BYTE_ARRAY */
+    int32_t type_length;           /* SchemaElement.TypeLength, < 0 = nil */
+    uint32_t max_rep, max_def;
+    uint32_t codec;                /* 0 = UNCOMPRESSED: the block is the page; else sizes are not checked */
+} pqo_chunk_in;
+
+typedef struct pqo_page_info {
+    int32_t type;              /* parquet.PageType: 0 DATA_PAGE, 2 DICTIONARY_PAGE, 3 DATA_PAGE_V2 */
+    int32_t encoding;
+    int32_t num_values;
+    int32_t compressed_size;   /* PageHeader.CompressedPageSize */
+    int32_t uncompressed_size;
+    int32_t def_len, rep_len;  /* V2 */
+    int32_t def_encoding, rep_encoding; /* V1 */
+    uint32_t is_compressed;    /* V2 (default true) */
+    uint64_t header_off;       /* offset in src of the header's first byte */
+    uint64_t data_off;         /* offset in src of the first byte behind the header */
+} pqo_page_info;
+
+/* infos: room for cap records.  Returns PQO_OK or the first error (the pages in front of it are
+ * reported).  *count = offsetReader.Count() when the loop ended.  More than cap pages:
+ * PQO_OUT_OF_RANGE_CAP. */
+int pqo_walk_chunk(const pqo_chunk_in *in, pqo_page_info *infos, uint32_t cap, uint32_t *n_pages,
+                   int64_t *count);
+
 /* ---- encoders, used only to generate inputs the reference itself would produce
  *      (encoding/hybrid-encoder.go, encoding/delta-binary-packed-encoder.go) ---- */
 int pqo_hybrid_encode(const int32_t *values, size_t n, int w, uint8_t *out, size_t cap,

@@ -37,6 +37,7 @@ EXPORTS = [
     "pq_delta_decode64", "pq_plain_decode", "pq_bool_plain_decode",
     "pq_levels_pack_dev", "pq_levels_pack", "pq_column_entries_dev", "pq_column_entries",
     "pq_delta_length_ba_decode", "pq_delta_ba_decode",
+    "pq_walk_chunks_dev", "pq_walk_chunks", "pq_chunk_page_descs",
 ]
 
 
@@ -69,6 +70,23 @@ DESC_DTYPE = np.dtype([("kind", "<u4"), ("flags", "<u4"), ("src_off", "<u8"), ("
 RESULT_DTYPE = np.dtype([("status", "<i4"), ("stage", "<i4"), ("detail", "<i4"),
                          ("n_decoded", "<u4"), ("not_null", "<u4"), ("n_levels", "<u4"),
                          ("consumed", "<u8")])
+# page-header walk (pq_walk_chunks): one record per column chunk in, one per page out
+WALK_HEADER_FAILED, WALK_SECOND_DICTIONARY, WALK_PAGE_TYPE, WALK_MISSING_HEADER = 19, 20, 21, 22
+WALK_NEGATIVE_NUM_VALUES, WALK_NEGATIVE_LEVELS_LENGTH, WALK_DICT_ENCODING, WALK_LEVEL_ENCODING = 23, 24, 25, 26
+WALK_VALUE_ENCODING, WALK_BLOCK_SIZE, WALK_UNCOMPRESSED_SIZE, WALK_SEEK = 27, 28, 29, 30
+CHUNK_DTYPE = np.dtype([("src_off", "<u8"), ("src_len", "<u8"), ("total_compressed_size", "<i8"),
+                        ("data_page_offset", "<i8"), ("dictionary_page_offset", "<i8"),
+                        ("has_dictionary_page_offset", "<u4"), ("physical_type", "<u4"), ("type_length", "<i4"),
+                        ("max_rep", "<u4"), ("max_def", "<u4"), ("codec", "<u4"), ("info_first", "<u4"),
+                        ("info_cap", "<u4")])
+PAGE_INFO_DTYPE = np.dtype([("type", "<i4"), ("encoding", "<i4"), ("num_values", "<i4"), ("compressed_size", "<i4"),
+                            ("uncompressed_size", "<i4"), ("def_len", "<i4"), ("rep_len", "<i4"),
+                            ("def_encoding", "<i4"), ("rep_encoding", "<i4"), ("is_compressed", "<u4"),
+                            ("header_off", "<u8"), ("data_off", "<u8")])
+CHUNK_RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_pages", "<u4"), ("count", "<i8")])
+CHUNK_LAYOUT_DTYPE = np.dtype([("values_off", "<u8"), ("levels_off", "<u8"), ("dict_off", "<u8"),
+                               ("delta_ba_room", "<u4"), ("_pad", "<u4")])
+assert CHUNK_DTYPE.itemsize == 72 and PAGE_INFO_DTYPE.itemsize == 56 and CHUNK_RESULT_DTYPE.itemsize == 16
 assert DESC_DTYPE.itemsize == C.sizeof(PageDesc) == 96
 assert RESULT_DTYPE.itemsize == C.sizeof(PageResult) == 32
 
@@ -137,6 +155,11 @@ def load():
                                            C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pq_bool_plain_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        for name in ("pq_walk_chunks_dev", "pq_walk_chunks"):
+            getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                           C.c_size_t, C.c_void_p]
+        lib.pq_chunk_page_descs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -347,8 +370,47 @@ class Context:
         if st != OK:
             raise PqError(st, self._lib.pq_last_error(self._h).decode())
 
+    # ---- page-header walk ----
+    def walk_chunks(self, src, chunks, infos_cap):
+        """ChunkReader.readPages over every chunk at once, host memory in and out -> (results, infos)."""
+        s = _np_u8(src)
+        ch = np.ascontiguousarray(chunks, dtype=CHUNK_DTYPE)
+        infos = np.zeros(max(int(infos_cap), 1), dtype=PAGE_INFO_DTYPE)
+        res = np.zeros(max(ch.size, 1), dtype=CHUNK_RESULT_DTYPE)
+        st = self._lib.pq_walk_chunks(self._h, _ptr(s), s.size, _ptr(ch), ch.size, _ptr(infos), int(infos_cap),
+                                      _ptr(res))
+        if st != OK:
+            raise PqError(st, "(pq_walk_chunks) " + self._lib.pq_last_error(self._h).decode())
+        return res[:ch.size], infos[:int(infos_cap)]
+
+    def walk_chunks_dev(self, d_src, src_bytes, chunks, d_infos, infos_cap):
+        """Device-resident walk: d_src / d_infos are device pointers -> results (host)."""
+        ch = np.ascontiguousarray(chunks, dtype=CHUNK_DTYPE)
+        res = np.zeros(max(ch.size, 1), dtype=CHUNK_RESULT_DTYPE)
+        st = self._lib.pq_walk_chunks_dev(self._h, C.c_void_p(d_src), int(src_bytes), _ptr(ch), ch.size,
+                                          C.c_void_p(d_infos), int(infos_cap), _ptr(res))
+        if st != OK:
+            raise PqError(st, "(pq_walk_chunks_dev) " + self._lib.pq_last_error(self._h).decode())
+        return res[:ch.size]
+
     def plan(self, descs):
         return Plan(self, descs)
+
+
+def chunk_page_descs(chunk, infos, layout):
+    """pq_chunk_page_descs: descriptors of an uncompressed chunk's data pages.  layout: a one-element
+    CHUNK_LAYOUT_DTYPE array, advanced in place.  -> (descs, dict_src, dict_dst, dict_bytes)"""
+    lib = load()
+    ch = np.ascontiguousarray(chunk, dtype=CHUNK_DTYPE).reshape(1)
+    inf = np.ascontiguousarray(infos, dtype=PAGE_INFO_DTYPE)
+    descs = np.zeros(max(inf.size, 1), dtype=DESC_DTYPE)
+    n = C.c_uint32(0)
+    a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    st = lib.pq_chunk_page_descs(_ptr(ch), _ptr(inf), inf.size, _ptr(layout), _ptr(descs), C.byref(n), C.byref(a),
+                                 C.byref(b), C.byref(c))
+    if st != OK:
+        raise PqError(st, "(pq_chunk_page_descs) " + status_string(st))
+    return descs[:n.value], a.value, b.value, c.value
 
 
 class Plan:

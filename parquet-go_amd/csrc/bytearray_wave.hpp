@@ -89,30 +89,31 @@ __device__ __forceinline__ ByteArrayLens ba_lengths_wave(uint32_t *window, const
                                                          uint32_t *area, int lane)
 {
     WaveDeltaResult lr = delta_wave<uint32_t>(window, S, len, 0x7fffffffu, area, lane, cap);
+    // More lengths declared than the area holds: decode as many as fit.  A stream that fails
+    // before that many ends Init with the reference's own error; only one that really yields
+    // them all is refused for want of room.
+    const bool over = lr.status == kOverCap;
+    if (over) lr = delta_wave<uint32_t>(window, S, len, cap, area, lane);
     if (lr.status == kNeedGeneric) {
         // a block layout other than 128 / 4: one lane decodes the lengths
         uint32_t total = 0;
         const bool parsed = delta_peek_total(S, len, &total);
-        if (parsed && total > cap) {
-            lr.status = kOverCap;
-        } else {
-            DeltaResult sr{PQ_OK, 0, 0, 0};
-            if (lane == 0) sr = delta_serial<uint32_t>(S, len, parsed ? total : 0u, area);
-            lr.status = (int32_t)uni((uint32_t)sr.status);
-            lr.n_decoded = uni(sr.n_decoded);
-            lr.consumed = ((uint64_t)uni((uint32_t)(sr.consumed >> 32)) << 32) | uni((uint32_t)sr.consumed);
-            lr.init_failed = uni(sr.init_failed);
-            lr.total = parsed ? total : 0u;
-        }
+        DeltaResult sr{PQ_OK, 0, 0, 0};
+        if (lane == 0) sr = delta_serial<uint32_t>(S, len, parsed ? min(total, cap) : 0u, area);
+        lr.status = (int32_t)uni((uint32_t)sr.status);
+        lr.n_decoded = uni(sr.n_decoded);
+        lr.consumed = ((uint64_t)uni((uint32_t)(sr.consumed >> 32)) << 32) | uni((uint32_t)sr.consumed);
+        lr.init_failed = uni(sr.init_failed);
+        lr.total = parsed ? total : 0u;
     }
+    if (over && !lr.init_failed && lr.status == PQ_OK && lr.n_decoded == cap) lr.status = kOverCap;
     ByteArrayLens r;
     r.status = lr.status;
     r.total = lr.total;
     r.consumed = lr.consumed;
     // asking for more than there are ends in io.EOF right behind the last one, which is not an
     // error of Init
-    r.ok = lr.status != kOverCap && !lr.init_failed && lr.n_decoded == lr.total &&
-           (lr.status == PQ_OK || lr.status == PQ_EOF);
+    r.ok = !over && !lr.init_failed && lr.n_decoded == lr.total && (lr.status == PQ_OK || lr.status == PQ_EOF);
     return r;
 }
 

@@ -82,7 +82,6 @@ int group_of(uint32_t kind)
     }
 }
 
-// Bytes per output value of a descriptor (0 = it writes no value output).
 // PQ_KIND_DELTA_LENGTH_BA / PQ_KIND_DELTA_BA when the descriptor (or its page's values) is one, else 0
 uint32_t byte_array_kind(const pq_page_desc &d)
 {
@@ -91,6 +90,7 @@ uint32_t byte_array_kind(const pq_page_desc &d)
     return k == PQ_KIND_DELTA_LENGTH_BA || k == PQ_KIND_DELTA_BA ? k : 0u;
 }
 
+// Bytes per output value of a descriptor (0 = it writes no fixed-width value output).
 uint32_t value_size(const pq_page_desc &d)
 {
     uint32_t k = d.kind;
@@ -181,6 +181,18 @@ const char *pq_status_string(int s)
     case PQ_BYTE_ARRAY_NEGATIVE_LEN: return "negative byte array length (the reference panics)";
     case PQ_BYTE_ARRAY_COUNT_MISMATCH: return "bytearray/delta: different number of suffixes and prefixes";
     case PQ_BYTE_ARRAY_INVALID_PREFIX: return "invalid prefix len in the stream";
+    case PQ_WALK_HEADER_FAILED: return "failed to read page header";
+    case PQ_WALK_SECOND_DICTIONARY: return "there should be only one dictionary";
+    case PQ_WALK_PAGE_TYPE: return "page type not supported";
+    case PQ_WALK_MISSING_HEADER: return "missing data page header";
+    case PQ_WALK_NEGATIVE_NUM_VALUES: return "negative NumValues";
+    case PQ_WALK_NEGATIVE_LEVELS_LENGTH: return "invalid levels byte length";
+    case PQ_WALK_DICT_ENCODING: return "only Encoding_PLAIN and Encoding_PLAIN_DICTIONARY are supported for dict values encoder";
+    case PQ_WALK_LEVEL_ENCODING: return "encoding not supported for definition and repetition level";
+    case PQ_WALK_VALUE_ENCODING: return "encoding not supported for the column type";
+    case PQ_WALK_BLOCK_SIZE: return "invalid size for compressed data";
+    case PQ_WALK_UNCOMPRESSED_SIZE: return "invalid size for decompressed data";
+    case PQ_WALK_SEEK: return "failed to set the read index to the start of the next page";
     case PQ_ERR_BAD_ARGUMENT: return "bad argument";
     case PQ_ERR_HIP: return "HIP runtime error";
     case PQ_ERR_NO_DEVICE: return "no HIP device";
@@ -655,21 +667,33 @@ static int byte_array_host(pq_ctx *ctx, uint32_t kind, const uint8_t *src, size_
     // room for every length the stream declares.  The suffix lengths of a DELTA_BYTE_ARRAY stream
     // start somewhere behind the prefix lengths: the two counts have to agree for Init to succeed,
     // so the first count sizes both.
-    const uint32_t cap = (uint32_t)std::min<uint64_t>(0x3fffffffull, std::max<uint64_t>(n, declared_lengths(src, src_len, nullptr)));
+    uint32_t cap = (uint32_t)std::min<uint64_t>(0x3fffffffull, std::max<uint64_t>(n, declared_lengths(src, src_len, nullptr)));
     const bool front = kind == PQ_KIND_DELTA_BA;
     pq_page_desc d;
-    std::memset(&d, 0, sizeof d);
-    d.kind = kind;
-    d.n_values = n;
-    d.dst_off = 0;
-    d.dst_cap = front ? (uint32_t)data_cap : 0;
-    d.dict_off = (data_cap + 15) / 16 * 16;
-    d.dict_len = cap;
-    const size_t bytes = (size_t)d.dict_off + 4 * ((front ? 2 : 1) * (size_t)cap + 1);
-    std::vector<uint8_t> tmp(bytes);
     pq_page_result r;
-    const int st = one_page(ctx, d, src, src_len, tmp.data(), bytes, nullptr, 0, nullptr, 0, &r);
-    if (st != PQ_OK) return st;
+    std::vector<uint8_t> tmp;
+    while (true) {
+        std::memset(&d, 0, sizeof d);
+        d.kind = kind;
+        d.n_values = n;
+        d.dst_off = 0;
+        d.dst_cap = front ? (uint32_t)data_cap : 0;
+        d.dict_off = (data_cap + 15) / 16 * 16;
+        d.dict_len = cap;
+        const size_t bytes = (size_t)d.dict_off + 4 * ((front ? 2 : 1) * (size_t)cap + 1);
+        tmp.resize(bytes);
+        const int st = one_page(ctx, d, src, src_len, tmp.data(), bytes, nullptr, 0, nullptr, 0, &r);
+        if (st != PQ_OK) return st;
+        // the suffix lengths may be more than the prefix lengths that sized the area: once more
+        // with room for as many as a stream of this size can hold, so that Init ends the way the
+        // reference's does (different number of suffixes and prefixes, or whatever comes first)
+        const uint32_t most = (uint32_t)std::min<uint64_t>(0x3fffffffull, 32ull * src_len + 256);
+        if (front && r.status == PQ_ERR_OUT_OF_RANGE && r.stage == PQ_STAGE_VALUES_INIT && cap < most) {
+            cap = most;
+            continue;
+        }
+        break;
+    }
     const bool init_bad = r.stage == PQ_STAGE_VALUES_INIT;
     const uint32_t nd = init_bad ? 0 : r.n_decoded;
     offsets[0] = 0;
@@ -697,6 +721,154 @@ int pq_delta_ba_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t
 {
     return byte_array_host(ctx, PQ_KIND_DELTA_BA, src, src_len, n, offsets, data, data_cap, n_decoded, consumed,
                            init_failed);
+}
+
+// ---- page-header walk -----------------------------------------------------------
+
+static int ensure_work(pq_ctx *ctx, size_t bytes);
+
+int pq_walk_chunks_dev(pq_ctx *ctx, const void *d_src, size_t src_bytes, const pq_chunk_desc *chunks,
+                       size_t n_chunks, pq_page_info *d_infos, size_t infos_cap, pq_chunk_result *results)
+{
+    if (!ctx || (n_chunks && (!chunks || !results)) || n_chunks > 0x7fffffffu) return PQ_ERR_BAD_ARGUMENT;
+    if (n_chunks == 0) return PQ_OK;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        const pq_chunk_desc &c = chunks[i];
+        // the kernel reads whole 16-byte lines around [src_off, src_off + src_len)
+        if (c.src_off > src_bytes || c.src_len > src_bytes - c.src_off || c.src_len > 0x7fffffffffffull)
+            return PQ_ERR_BAD_ARGUMENT;
+        if ((uint64_t)c.info_first + c.info_cap > infos_cap) return PQ_ERR_BAD_ARGUMENT;
+        if (c.src_len && !d_src) return PQ_ERR_BAD_ARGUMENT;
+        if (c.info_cap && !d_infos) return PQ_ERR_BAD_ARGUMENT;
+    }
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t cbytes = n_chunks * sizeof(pq_chunk_desc), rbytes = n_chunks * sizeof(pq_chunk_result);
+    const size_t roff = (cbytes + 15) / 16 * 16;
+    const int st = ensure_work(ctx, roff + rbytes);
+    if (st != PQ_OK) return st;
+    uint8_t *w = static_cast<uint8_t *>(ctx->work);
+    PQ_HIP(ctx, hipMemcpyAsync(w, chunks, cbytes, hipMemcpyHostToDevice, ctx->stream));
+    PQ_HIP(ctx, pq::launch_walk_chunks(ctx->stream, reinterpret_cast<const pq_chunk_desc *>(w), (uint32_t)n_chunks, d_src,
+                                       d_infos, reinterpret_cast<pq_chunk_result *>(w + roff)));
+    PQ_HIP(ctx, hipMemcpyAsync(results, w + roff, rbytes, hipMemcpyDeviceToHost, ctx->stream));
+    PQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PQ_OK;
+}
+
+int pq_walk_chunks(pq_ctx *ctx, const void *src, size_t src_bytes, const pq_chunk_desc *chunks, size_t n_chunks,
+                   pq_page_info *infos, size_t infos_cap, pq_chunk_result *results)
+{
+    if (!ctx || (src_bytes && !src) || (infos_cap && !infos)) return PQ_ERR_BAD_ARGUMENT;
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    int st = ensure_stage(ctx, 0, src_bytes + 32);
+    if (st == PQ_OK) st = ensure_stage(ctx, 1, infos_cap * sizeof(pq_page_info) + 16);
+    if (st != PQ_OK) return st;
+    if (src_bytes) PQ_HIP(ctx, hipMemcpyAsync(ctx->stage[0], src, src_bytes, hipMemcpyHostToDevice, ctx->stream));
+    st = pq_walk_chunks_dev(ctx, ctx->stage[0], src_bytes, chunks, n_chunks, static_cast<pq_page_info *>(ctx->stage[1]),
+                            infos_cap, results);
+    if (st != PQ_OK) return st;
+    if (infos_cap)
+        PQ_HIP(ctx, hipMemcpyAsync(infos, ctx->stage[1], infos_cap * sizeof(pq_page_info), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    PQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PQ_OK;
+}
+
+int pq_chunk_page_descs(const pq_chunk_desc *chunk, const pq_page_info *infos, uint32_t n_pages,
+                        pq_chunk_layout *layout, pq_page_desc *descs, uint32_t *n_descs, uint64_t *dict_src,
+                        uint64_t *dict_dst, uint64_t *dict_bytes)
+{
+    if (!chunk || !layout || !n_descs || (n_pages && (!infos || !descs))) return PQ_ERR_BAD_ARGUMENT;
+    if (chunk->codec != 0) return PQ_ERR_BAD_ARGUMENT;
+    uint32_t es = 0;  // bytes per fixed-width value
+    switch (chunk->physical_type) {
+    case 0: break;             // BOOLEAN
+    case 1: case 4: es = 4; break;  // INT32, FLOAT
+    case 2: case 5: es = 8; break;  // INT64, DOUBLE
+    case 6: break;             // BYTE_ARRAY
+    default: return PQ_ERR_BAD_ARGUMENT;
+    }
+    uint32_t dict_len = 0;
+    uint64_t d_src = 0, d_dst = 0, d_bytes = 0;
+    uint32_t out = 0;
+    for (uint32_t i = 0; i < n_pages; ++i) {
+        const pq_page_info &p = infos[i];
+        if (p.type == 2) {
+            // a PLAIN dictionary of fixed-width values is its page body, little endian
+            // (dictPageReader.read, layout/page-dict.go:59-77; types/int32.go:56-72)
+            if (es == 0 || p.num_values < 0) return PQ_ERR_BAD_ARGUMENT;
+            if ((uint64_t)p.num_values * es > (uint64_t)(uint32_t)p.uncompressed_size)
+                return PQ_UNEXPECTED_EOF;  // "unexpected number of values" (:70-77)
+            dict_len = (uint32_t)p.num_values;
+            d_src = chunk->src_off + p.data_off;
+            d_dst = (layout->dict_off + 7) / 8 * 8;
+            d_bytes = (uint64_t)dict_len * es;
+            layout->dict_off = d_dst + d_bytes;
+            continue;
+        }
+        if (p.type != 0 && p.type != 3) return PQ_ERR_BAD_ARGUMENT;
+        pq_page_desc d;
+        std::memset(&d, 0, sizeof d);
+        d.kind = p.type == 0 ? PQ_KIND_PAGE_V1 : PQ_KIND_PAGE_V2;
+        d.src_off = chunk->src_off + p.data_off;
+        d.src_len = (uint64_t)(uint32_t)p.compressed_size;
+        d.n_values = (uint32_t)p.num_values;
+        d.max_rep = chunk->max_rep;
+        d.max_def = chunk->max_def;
+        d.rep_len = (uint32_t)p.rep_len;
+        d.def_len = (uint32_t)p.def_len;
+        const int32_t enc = p.encoding == 2 ? 8 : p.encoding;  // PLAIN_DICTIONARY (layout/page-dict.go:145-147)
+        const uint32_t t = chunk->physical_type;
+        uint64_t value_bytes = 0;
+        if (enc == 8) {
+            if (es == 0) return PQ_ERR_BAD_ARGUMENT;
+            d.value_kind = PQ_KIND_DICT;
+            d.elem_size = es;
+            d.dict_off = d_dst;
+            d.dict_len = dict_len;
+            value_bytes = (uint64_t)d.n_values * es;
+        } else if (enc == 0 && es != 0) {
+            d.value_kind = PQ_KIND_PLAIN;
+            d.elem_size = es;
+            value_bytes = (uint64_t)d.n_values * es;
+        } else if (enc == 0 && t == 0) {
+            d.value_kind = PQ_KIND_BOOL_PLAIN;
+            value_bytes = (uint64_t)d.n_values * 4;
+        } else if (enc == 3 && t == 0) {
+            d.value_kind = PQ_KIND_BOOL_RLE;
+            value_bytes = (uint64_t)d.n_values * 4;
+        } else if (enc == 5 && (t == 1 || t == 2)) {
+            d.value_kind = t == 1 ? PQ_KIND_DELTA32 : PQ_KIND_DELTA64;
+            value_bytes = (uint64_t)d.n_values * es;
+        } else if ((enc == 6 || enc == 7) && t == 6) {
+            d.value_kind = enc == 6 ? PQ_KIND_DELTA_LENGTH_BA : PQ_KIND_DELTA_BA;
+        } else {
+            return PQ_ERR_BAD_ARGUMENT;
+        }
+        if (d.value_kind == PQ_KIND_DELTA_LENGTH_BA || d.value_kind == PQ_KIND_DELTA_BA) {
+            const bool front = d.value_kind == PQ_KIND_DELTA_BA;
+            const uint64_t room = front ? layout->delta_ba_room : d.src_len;
+            d.dst_off = layout->values_off;
+            d.dst_cap = front ? layout->delta_ba_room : 0;
+            d.dict_off = (d.dst_off + room + 3) / 4 * 4;
+            d.dict_len = d.n_values;
+            layout->values_off = d.dict_off + 4 * ((front ? 2ull : 1ull) * d.n_values + 1);
+        } else {
+            const uint32_t vs = value_size(d);
+            d.dst_off = (layout->values_off + vs - 1) / vs * vs;
+            layout->values_off = d.dst_off + value_bytes;
+        }
+        layout->levels_off = (layout->levels_off + 3) / 4 * 4;
+        d.rep_off = layout->levels_off;
+        d.def_off = d.rep_off + 4ull * d.n_values;
+        layout->levels_off = d.def_off + 4ull * d.n_values;
+        descs[out++] = d;
+    }
+    *n_descs = out;
+    if (dict_src) *dict_src = d_src;
+    if (dict_dst) *dict_dst = d_dst;
+    if (dict_bytes) *dict_bytes = d_bytes;
+    return PQ_OK;
 }
 
 // ---- level post-processing ----------------------------------------------------

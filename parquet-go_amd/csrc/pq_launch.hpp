@@ -63,4 +63,8 @@ hipError_t launch_column_entries(hipStream_t s, const int32_t *d_def, const int3
                                  uint32_t *d_validity, int32_t *d_entry_def, pq_entries_result *d_result,
                                  void *d_work);
 
+// Page-header walk (walk.hip): one wave per chunk; d_infos / d_results as in pq_walk_chunks_dev.
+hipError_t launch_walk_chunks(hipStream_t s, const pq_chunk_desc *d_chunks, uint32_t n_chunks, const void *d_src,
+                              pq_page_info *d_infos, pq_chunk_result *d_results);
+
 } // namespace pq

@@ -495,6 +495,68 @@ private:
     HybridDecoder decoder_;
 };
 
+// ---- types.ByteArrayDeltaLengthDecoder / ByteArrayDeltaDecoder (types/byte-array.go:168-219, 279-348) ----
+// One DecodeValues call on a fresh decoder, like the reference's page readers make.  A value is a
+// []byte: here a std::vector<uint8_t>.  Init reports what the reference's Init reports (all
+// lengths are decoded there); a DELTA_BYTE_ARRAY page whose values outgrow the room first guessed
+// is decoded again with more.
+using ByteArray = std::vector<uint8_t>;
+
+class ByteArrayDecoderBase {
+public:
+    Error Init(Reader &r)
+    {
+        reader_ = &r;
+        std::vector<ByteArray> none;
+        return DecodeValues(none.data(), 0).second;
+    }
+
+    std::pair<int, Error> DecodeValues(ByteArray *dest, uint32_t n)
+    {
+        if (!reader_) return {0, Error(PQ_NOT_INITIALIZED)};
+        const uint8_t *src = reader_->cursor();
+        const size_t len = reader_->Len();
+        std::vector<uint32_t> offsets((size_t)n + 1);
+        size_t room = front_ ? 4 * len + 4096 : len;
+        while (true) {
+            std::vector<uint8_t> data(room ? room : 1);
+            uint32_t count = 0;
+            uint64_t consumed = 0;
+            int init_failed = 0;
+            const int st = front_ ? pq_delta_ba_decode(dev_.ctx(), src, len, n, offsets.data(), data.data(), room, &count,
+                                                       &consumed, &init_failed)
+                                  : pq_delta_length_ba_decode(dev_.ctx(), src, len, n, offsets.data(), data.data(), &count,
+                                                              &consumed, &init_failed);
+            if (st == PQ_ERR_OUT_OF_RANGE && front_ && !init_failed && room < 0xffffffffull) {
+                room = std::min<size_t>(0xffffffffull, room * 4);
+                continue;
+            }
+            check_library(st, "pq_delta_(length_)ba_decode");
+            for (uint32_t i = 0; i < count; ++i) dest[i].assign(data.begin() + offsets[i], data.begin() + offsets[i + 1]);
+            if (!init_failed && n) reader_->advance((size_t)consumed);
+            return {(int)count, Error(st)};
+        }
+    }
+
+protected:
+    ByteArrayDecoderBase(Device &dev, bool front) : dev_(dev), front_(front) {}
+
+private:
+    Device &dev_;
+    bool front_;
+    Reader *reader_ = nullptr;
+};
+
+class ByteArrayDeltaLengthDecoder final : public ByteArrayDecoderBase {
+public:
+    explicit ByteArrayDeltaLengthDecoder(Device &dev) : ByteArrayDecoderBase(dev, false) {}
+};
+
+class ByteArrayDeltaDecoder final : public ByteArrayDecoderBase {
+public:
+    explicit ByteArrayDeltaDecoder(Device &dev) : ByteArrayDecoderBase(dev, true) {}
+};
+
 // ---- layout.decodePackedArray (layout/helpers.go:68-90) ------------------------------------
 // levelDecoder = a Decoder that knows its maximum level (layout/level-decoder.go:5-18).
 struct LevelDecoder {

@@ -287,3 +287,100 @@ def delta_ba_encode(values, block=128, miniblocks=4):
         prev = v
     return np.concatenate([delta_encode(np.array(plens, dtype=np.int32), 32, block, miniblocks),
                            delta_length_ba_encode(suffixes, block, miniblocks)]).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------
+# Thrift compact protocol: page headers (parquet/parquet.thrift PageHeader and its members)
+
+def _zz(v):
+    return (v << 1) ^ (v >> 63) if v >= 0 else ((-v) << 1) - 1
+
+
+def thrift_value(kind, value):
+    """Bytes of one value.  kind: "i32" / "i64" / "i16" / "byte" / "double" / "binary" / "struct" (value = field
+    list) / ("list", elem kind) / ("map", key kind, value kind)."""
+    if kind in ("i16", "i32", "i64"):
+        return bytes(uleb128(_zz(int(value))))
+    if kind == "byte":
+        return bytes([value & 0xFF])
+    if kind == "double":
+        return np.array([value], dtype="<f8").tobytes()
+    if kind == "binary":
+        return bytes(uleb128(len(value))) + bytes(value)
+    if kind == "struct":
+        return thrift_struct(value)
+    if kind == "bool":                      # inside a collection
+        return bytes([1 if value else 2])
+    if kind[0] in ("list", "set"):
+        n, et = len(value), _CT[kind[1] if isinstance(kind[1], str) else kind[1][0]]
+        head = bytes([(n << 4) | et]) if n < 15 else bytes([0xF0 | et]) + bytes(uleb128(n))
+        return head + b"".join(thrift_value(kind[1], v) for v in value)
+    if kind[0] == "map":
+        if not value:
+            return b"\x00"
+        kt, vt = _CT[kind[1]], _CT[kind[2]]
+        return bytes(uleb128(len(value))) + bytes([(kt << 4) | vt]) + b"".join(
+            thrift_value(kind[1], k) + thrift_value(kind[2], v) for k, v in value)
+    raise ValueError(kind)
+
+
+_CT = {"bool": 1, "byte": 3, "i16": 4, "i32": 5, "i64": 6, "double": 7, "binary": 8, "list": 9, "set": 10, "map": 11,
+       "struct": 12}
+
+
+def thrift_struct(fields):
+    """fields: (id, kind, value) in any order of ids; short-form headers where the id delta allows."""
+    out, last = bytearray(), 0
+    for fid, kind, value in fields:
+        if kind == "bool":
+            ct = 1 if value else 2
+        else:
+            ct = _CT[kind if isinstance(kind, str) else kind[0]]
+        delta = fid - last
+        if 0 < delta <= 15:
+            out.append((delta << 4) | ct)
+        else:
+            out.append(ct)
+            out += bytes(uleb128(_zz(fid)))
+        last = fid
+        if kind != "bool":
+            out += thrift_value(kind, value)
+    out.append(0)
+    return bytes(out)
+
+
+def statistics(rng=None):
+    """A Statistics struct (binary min / max, counts), which the walk has to step over."""
+    rng = rng or np.random.default_rng(0)
+    return [(1, "binary", bytes(rng.integers(0, 256, size=int(rng.integers(0, 40)), dtype=np.uint8))),
+            (2, "binary", b"ab"), (3, "i64", int(rng.integers(0, 1000))), (4, "i64", 77),
+            (5, "binary", bytes(rng.integers(0, 256, size=int(rng.integers(0, 200)), dtype=np.uint8))),
+            (6, "binary", b"")]
+
+
+def page_header(page_type, uncompressed, compressed, data=None, dictionary=None, v2=None, crc=None, extra=()):
+    """PageHeader bytes.  data = (num_values, encoding, def_encoding, rep_encoding[, statistics fields]);
+    dictionary = (num_values, encoding[, is_sorted]); v2 = (num_values, num_nulls, num_rows, encoding, def_len,
+    rep_len[, is_compressed[, statistics fields]]); extra: further (id, kind, value) fields."""
+    f = [(1, "i32", page_type), (2, "i32", uncompressed), (3, "i32", compressed)]
+    if crc is not None:
+        f.append((4, "i32", crc))
+    if data is not None:
+        sub = [(1, "i32", data[0]), (2, "i32", data[1]), (3, "i32", data[2]), (4, "i32", data[3])]
+        if len(data) > 4:
+            sub.append((5, "struct", data[4]))
+        f.append((5, "struct", sub))
+    if dictionary is not None:
+        sub = [(1, "i32", dictionary[0]), (2, "i32", dictionary[1])]
+        if len(dictionary) > 2:
+            sub.append((3, "bool", dictionary[2]))
+        f.append((7, "struct", sub))
+    if v2 is not None:
+        sub = [(k + 1, "i32", v2[k]) for k in range(6)]
+        if len(v2) > 6 and v2[6] is not None:
+            sub.append((7, "bool", v2[6]))
+        if len(v2) > 7:
+            sub.append((8, "struct", v2[7]))
+        f.append((8, "struct", sub))
+    f += list(extra)
+    return thrift_struct(f)

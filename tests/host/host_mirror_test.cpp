@@ -726,6 +726,110 @@ static void TestDataPages(Device &dev)
     }
 }
 
+// ---- types.ByteArrayDeltaLengthDecoder / ByteArrayDeltaDecoder (no reference test; streams as the
+//      reference's encoders lay them out, types/byte-array.go:148-158,264-275; checked against the
+//      values fed in and against the oracle) -------------------------------------------------------
+static std::vector<uint8_t> delta32_stream(const std::vector<int32_t> &v)
+{
+    std::vector<uint8_t> s(v.size() * 5 + 64);
+    size_t len = 0;
+    if (pqo_delta_encode32(v.data(), v.size(), 128, 4, s.data(), s.size(), &len) != 0) std::abort();
+    s.resize(len);
+    return s;
+}
+
+static void TestByteArrayDecoders(Device &dev)
+{
+    const uint32_t n = 5000;
+    std::vector<ByteArray> vals(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i && rnd() % 3 == 0) {  // extend or cut the value in front
+            vals[i] = vals[i - 1];
+            vals[i].resize(rnd() % (vals[i].size() + 1));
+        }
+        for (uint32_t k = rnd() % 9; k > 0; --k) vals[i].push_back((uint8_t)rnd());
+    }
+    std::vector<int32_t> lens(n), plens(n), slens(n);
+    std::vector<uint8_t> body, sbody;
+    for (uint32_t i = 0; i < n; ++i) {
+        lens[i] = (int32_t)vals[i].size();
+        body.insert(body.end(), vals[i].begin(), vals[i].end());
+        size_t p = 0;
+        if (i)
+            while (p < vals[i].size() && p < vals[i - 1].size() && vals[i][p] == vals[i - 1][p]) ++p;
+        plens[i] = (int32_t)p;
+        slens[i] = (int32_t)(vals[i].size() - p);
+        sbody.insert(sbody.end(), vals[i].begin() + p, vals[i].end());
+    }
+    std::vector<uint8_t> ls = delta32_stream(lens);
+    ls.insert(ls.end(), body.begin(), body.end());
+    std::vector<uint8_t> fs = delta32_stream(plens), tail = delta32_stream(slens);
+    fs.insert(fs.end(), tail.begin(), tail.end());
+    fs.insert(fs.end(), sbody.begin(), sbody.end());
+    {
+        std::printf("    delta length: all values\n");
+        Reader r(ls);
+        ByteArrayDeltaLengthDecoder d(dev);
+        CHECK(!d.Init(r));
+        std::vector<ByteArray> got(n + 5);
+        auto res = d.DecodeValues(got.data(), n + 5);  // io.EOF with fewer values is acceptable
+        CHECK(res.second.is(PQ_EOF));
+        CHECK_EQ(res.first, n);
+        got.resize(n);
+        CHECK(got == vals);
+        CHECK_EQ(r.Len(), 0);
+    }
+    {
+        std::printf("    delta: all values\n");
+        Reader r(fs);
+        ByteArrayDeltaDecoder d(dev);
+        CHECK(!d.Init(r));
+        std::vector<ByteArray> got(n);
+        auto res = d.DecodeValues(got.data(), n);
+        CHECK(!res.second);
+        CHECK_EQ(res.first, n);
+        CHECK(got == vals);
+        CHECK_EQ(r.Len(), 0);
+        // same call through the oracle
+        std::vector<uint32_t> off(n + 1);
+        std::vector<uint8_t> data(body.size() + 1);
+        uint32_t cnt = 0;
+        CHECK_EQ(pqo_delta_ba_decode(fs.data(), fs.size(), n, off.data(), data.data(), body.size(), &cnt, nullptr, nullptr,
+                                     nullptr), 0);
+        CHECK_EQ(cnt, n);
+        data.resize(body.size());
+        CHECK(data == body);
+    }
+    {  // a prefix longer than the value in front: "invalid prefix len", count 0 (:328-336)
+        std::printf("    delta: invalid prefix\n");
+        std::vector<int32_t> bad = plens;
+        bad[100] = lens[99] + 1;
+        std::vector<uint8_t> s = delta32_stream(bad);
+        s.insert(s.end(), tail.begin(), tail.end());
+        s.insert(s.end(), sbody.begin(), sbody.end());
+        Reader r(s);
+        ByteArrayDeltaDecoder d(dev);
+        CHECK(!d.Init(r));
+        std::vector<ByteArray> got(n);
+        auto res = d.DecodeValues(got.data(), n);
+        CHECK(res.second.is(PQ_BYTE_ARRAY_INVALID_PREFIX));
+        CHECK_EQ(res.first, 0);
+    }
+    {  // unequal counts fail Init (:301-308); truncated lengths fail Init too
+        std::printf("    delta: unequal counts\n");
+        std::vector<int32_t> fewer(plens.begin(), plens.begin() + 4000);
+        std::vector<uint8_t> s = delta32_stream(fewer);
+        s.insert(s.end(), tail.begin(), tail.end());
+        Reader r(s);
+        ByteArrayDeltaDecoder d(dev);
+        CHECK(d.Init(r).is(PQ_BYTE_ARRAY_COUNT_MISMATCH));
+        std::vector<uint8_t> cut(ls.begin(), ls.begin() + 40);
+        Reader r2(cut);
+        ByteArrayDeltaLengthDecoder d2(dev);
+        CHECK(d2.Init(r2).is(PQ_UNEXPECTED_EOF));
+    }
+}
+
 int main()
 {
     Device dev(0);
@@ -744,12 +848,18 @@ int main()
         {"TestDictDecoder_int64", [&] { TestDictDecoder<int64_t>(dev); }},
         {"TestDecodePackedArray", [&] { TestDecodePackedArray(dev); }},
         {"TestDataPages", [&] { TestDataPages(dev); }},
+        {"TestByteArrayDecoders", [&] { TestByteArrayDecoders(dev); }},
     };
     for (auto &t : tests) {
         int before = g_failed;
         std::printf("=== RUN   %s\n", t.name);
         std::fflush(stdout);
-        t.fn();
+        try {
+            t.fn();
+        } catch (const std::exception &e) {  // the mirror throws only for library-level failures
+            std::printf("    exception: %s\n", e.what());
+            ++g_failed;
+        }
         std::printf("--- %s: %s\n", g_failed == before ? "PASS" : "FAIL", t.name);
     }
     std::printf("%d checks, %d failed\n", g_checks, g_failed);

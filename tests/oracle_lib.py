@@ -215,6 +215,38 @@ def delta_ba_decode(src, n, data_cap):
                 offsets=offsets[:nd.value + 1].copy(), data=data[:int(offsets[nd.value])].copy())
 
 
+class ChunkIn(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("src_len", C.c_uint64), ("total_compressed_size", C.c_int64),
+                ("data_page_offset", C.c_int64), ("dictionary_page_offset", C.c_int64),
+                ("has_dictionary_page_offset", C.c_uint32), ("physical_type", C.c_uint32),
+                ("type_length", C.c_int32), ("max_rep", C.c_uint32), ("max_def", C.c_uint32), ("codec", C.c_uint32)]
+
+
+WALK_INFO_DTYPE = np.dtype([("type", "<i4"), ("encoding", "<i4"), ("num_values", "<i4"), ("compressed_size", "<i4"),
+                            ("uncompressed_size", "<i4"), ("def_len", "<i4"), ("rep_len", "<i4"),
+                            ("def_encoding", "<i4"), ("rep_encoding", "<i4"), ("is_compressed", "<u4"),
+                            ("header_off", "<u8"), ("data_off", "<u8")])
+
+
+def walk_chunk(src, total_compressed_size, data_page_offset, dictionary_page_offset=None, physical_type=1,
+               type_length=-1, max_rep=0, max_def=0, codec=0, cap=4096):
+    """ChunkReader.readPages -> dict(status, infos[:n_pages], count)"""
+    s = _u8(src)
+    cin = ChunkIn()
+    cin.src = s.ctypes.data if s.size else None
+    cin.src_len = s.size
+    cin.total_compressed_size = total_compressed_size
+    cin.data_page_offset = data_page_offset
+    cin.has_dictionary_page_offset = 0 if dictionary_page_offset is None else 1
+    cin.dictionary_page_offset = dictionary_page_offset or 0
+    cin.physical_type, cin.type_length = physical_type, type_length
+    cin.max_rep, cin.max_def, cin.codec = max_rep, max_def, codec
+    infos = np.zeros(max(cap, 1), dtype=WALK_INFO_DTYPE)
+    n, count = C.c_uint32(0), C.c_int64(0)
+    st = lib().pqo_walk_chunk(C.byref(cin), _ptr(infos), C.c_uint32(cap), C.byref(n), C.byref(count))
+    return dict(status=st, infos=infos[:n.value].copy(), count=count.value)
+
+
 def levels_pack(levels, w):
     """PackedArray bytes of AppendSingle x n and, for n > 0, Flush."""
     lv = np.ascontiguousarray(levels, dtype=np.int32)

@@ -8,6 +8,8 @@ device-resident, HIP-event timed.  Prints one JSON object per configuration.
   C4  nested V1 data pages: rep (w=1) + def (w=2) levels + dictionary values
   C2x INT64 delta at other miniblock widths / INT32 delta
   P   PLAIN int64 / int32 values, BOOLEAN PLAIN bits, BOOLEAN RLE runs
+  B   DELTA_LENGTH_BYTE_ARRAY (random 4..20-byte values) and DELTA_BYTE_ARRAY (sorted words, shared prefixes):
+      value bytes + uint32 offsets out
   L   level post-processing over 100 M slots: column entries (validity, offsets, returned definition
       levels) of a REPEATED and of an OPTIONAL column, PackedArray bytes of the levels
 """
@@ -234,6 +236,56 @@ def bench_plain(ctx, stream, pages, n, kind, es, label):
     plan.close()
 
 
+def bench_byte_array(ctx, stream, pages, n, front):
+    """front: DELTA_BYTE_ARRAY over sorted 3..13-letter words; else DELTA_LENGTH_BYTE_ARRAY over random bytes."""
+    rng = np.random.default_rng(8)
+    distinct = min(pages, 8)
+    streams, flats, offs_want = [], [], []
+    for p in range(distinct):
+        if front:
+            vals = sorted(bytes(rng.integers(97, 123, size=int(rng.integers(3, 14)), dtype=np.uint8)) for _ in range(n))
+            streams.append(synth.delta_ba_encode(vals))
+        else:
+            vals = [bytes(rng.integers(0, 256, size=int(rng.integers(4, 21)), dtype=np.uint8)) for _ in range(n)]
+            streams.append(synth.delta_length_ba_encode(vals))
+        flats.append(np.frombuffer(b"".join(vals), dtype=np.uint8))
+        offs_want.append(np.concatenate([[0], np.cumsum([len(v) for v in vals])]).astype(np.uint32))
+    room = (max(f.size for f in flats) + 15) // 16 * 16
+    if not front:
+        room = (max(s.size for s in streams) + 15) // 16 * 16
+    while len(streams) < pages:
+        streams.append(streams[len(streams) % distinct])
+    src, offs, lens = pack_pages(streams)
+    area = 4 * ((2 if front else 1) * n + 1)
+    area = (area + 15) // 16 * 16
+    descs = np.zeros(pages, dtype=capi.DESC_DTYPE)
+    descs["kind"] = capi.KIND_DELTA_BA if front else capi.KIND_DELTA_LENGTH_BA
+    descs["src_off"], descs["src_len"], descs["n_values"] = offs, lens, n
+    descs["dst_off"] = np.arange(pages, dtype=np.uint64) * np.uint64(room + area)
+    descs["dict_off"] = descs["dst_off"] + np.uint64(room)
+    descs["dict_len"] = n
+    descs["dst_cap"] = room if front else 0
+    t_src = torch.from_numpy(src).to(DEV)
+    t_out = torch.empty(pages * (room + area), dtype=torch.uint8, device=DEV)
+    plan = ctx.plan(descs)
+    fn = lambda: plan.run(t_src.data_ptr(), src.size, t_out.data_ptr(), t_out.numel())
+    t = timed(fn, stream, steps=6, warmup=1)
+    res = plan.results()
+    assert (res["status"] == 0).all() and (res["n_decoded"] == n).all(), res[:4]
+    got = t_out.cpu().numpy().reshape(pages, room + area)
+    out_bytes = 0
+    for p in range(pages):
+        f, o = flats[p % distinct], offs_want[p % distinct]
+        out_bytes += f.size + 4 * (n + 1)
+        if p in (0, pages // 2, pages - 1):
+            assert np.array_equal(got[p, :f.size], f)
+            assert np.array_equal(got[p, room: room + 4 * (n + 1)].view(np.uint32), o)
+    report("B DELTA_BYTE_ARRAY sorted words" if front else "B DELTA_LENGTH_BYTE_ARRAY 4..20-byte values",
+           int(lens.sum()), out_bytes, t, {"pages": pages, "values_per_page": n,
+                                           "value_bytes_per_page": int(flats[0].size)})
+    plan.close()
+
+
 def bench_levels(ctx, stream, n):
     g = torch.Generator(device=DEV)
     g.manual_seed(7)
@@ -289,6 +341,9 @@ def main():
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_PLAIN, 4, "P PLAIN int32")
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_BOOL_PLAIN, 4, "P BOOLEAN PLAIN")
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_BOOL_RLE, 4, "P BOOLEAN RLE (mean run 24)")
+    if want("bytes"):
+        bench_byte_array(ctx, stream, args.pages, 20000, False)
+        bench_byte_array(ctx, stream, args.pages, 20000, True)
     if want("levels"):
         bench_levels(ctx, stream, 100_000_000)
     print("elapsed %.1fs" % (time.time() - t0), file=sys.stderr)
