@@ -48,30 +48,51 @@ __device__ __forceinline__ bool delta_peek_total(const uint8_t *S, int64_t len, 
     return true;
 }
 
-// dst[0, n) = src[0, n): any alignment on either side, 4 bytes per lane and step.
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // 16 bytes at a 4-byte boundary
+
+// dst[0, n) = src[0, n): any alignment on either side.  16 bytes per lane and step, four steps
+// in flight; the destination pieces are 16-byte aligned, the source words are funnel-shifted.
 __device__ __forceinline__ void wave_copy_bytes(uint8_t *dst, const uint8_t *src, uint64_t n, int lane)
 {
     if (n == 0) return;
-    // bytes in front of the first 4-byte aligned destination address
-    const uint32_t head = (uint32_t)min((uint64_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u), n);
+    // bytes in front of the first 16-byte aligned destination address
+    const uint32_t head = (uint32_t)min((uint64_t)((16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u), n);
     if ((uint32_t)lane < head) dst[lane] = src[lane];
     dst += head;
     src += head;
     n -= head;
-    const uint64_t words = n >> 2;
+    const uint64_t pieces = n >> 4;
     const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3u) * 8u;
     const uint32_t *s32 = reinterpret_cast<const uint32_t *>(reinterpret_cast<uintptr_t>(src) & ~(uintptr_t)3);
-    uint32_t *d32 = reinterpret_cast<uint32_t *>(dst);
-    if (sh == 0u) {
-        for (uint64_t i = (uint64_t)lane; i < words; i += kWave) __builtin_nontemporal_store(s32[i], d32 + i);
-    } else {
-        // word i of the destination straddles aligned source words i and i + 1; the second one
-        // holds at least one byte of the source (n >= 4 (i + 1)), so both lie inside its pages
-        for (uint64_t i = (uint64_t)lane; i < words; i += kWave)
-            __builtin_nontemporal_store(__builtin_amdgcn_alignbit(s32[i + 1], s32[i], sh), d32 + i);
+    constexpr int kInFlight = 4;
+    for (uint64_t i0 = (uint64_t)lane; i0 < pieces; i0 += (uint64_t)kWave * kInFlight) {
+        u32x4_a4 v[kInFlight];
+        uint32_t e[kInFlight];
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+            const uint64_t i = i0 + (uint64_t)kWave * u;
+            if (i < pieces) {
+                v[u] = *reinterpret_cast<const u32x4_a4 *>(s32 + 4 * i);
+                // the word behind the piece holds at least one source byte when the source is
+                // not word aligned (n >= 16 (i + 1)); it is not touched otherwise
+                e[u] = sh ? s32[4 * i + 4] : 0u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kInFlight; ++u) {
+            const uint64_t i = i0 + (uint64_t)kWave * u;
+            if (i < pieces) {
+                u32x4_t o;
+                o.x = __builtin_amdgcn_alignbit(v[u].y, v[u].x, sh);
+                o.y = __builtin_amdgcn_alignbit(v[u].z, v[u].y, sh);
+                o.z = __builtin_amdgcn_alignbit(v[u].w, v[u].z, sh);
+                o.w = __builtin_amdgcn_alignbit(e[u], v[u].w, sh);
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(dst) + i);
+            }
+        }
     }
-    const uint32_t tail = (uint32_t)(n & 3u);
-    if ((uint32_t)lane < tail) dst[4 * words + lane] = src[4 * words + lane];
+    const uint32_t tail = (uint32_t)(n & 15u);
+    if ((uint32_t)lane < tail) dst[16 * pieces + lane] = src[16 * pieces + lane];
 }
 
 // Every length an INT32 DELTA_BINARY_PACKED stream declares, into area[0, total): what
@@ -144,38 +165,74 @@ __device__ __forceinline__ ByteArrayResult delta_length_ba_wave(uint32_t *window
     uint64_t carry = 0;
     uint32_t done = 0;
     int32_t status = PQ_OK;
-    // offsets[i + 1] takes the place of length i + 1: a chunk's lengths are loaded before the
-    // chunk in front of it stores
-    auto load_len = [&](uint32_t i) -> int32_t {
-        return i < m ? (int32_t)__hip_atomic_load(area + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    constexpr uint32_t kPer = 4;  // lengths per lane and step
+    // offsets[i + 1] takes the place of length i + 1: a step's lengths are loaded before the
+    // step in front of it stores
+    auto load_lens = [&](uint32_t i0, int32_t *c) {
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k)
+            c[k] = i0 + k < m ? (int32_t)__hip_atomic_load(area + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     };
-    int32_t cur = load_len((uint32_t)lane);
-    for (uint32_t base = 0; base < m; base += kWave) {
-        const int32_t next = load_len(base + kWave + (uint32_t)lane);
-        const uint32_t i = base + (uint32_t)lane;
-        const bool live = i < m;
-        const bool neg = live && cur < 0;
-        const uint64_t incl = carry + wave_scan_u64(live && !neg ? (uint64_t)(uint32_t)cur : 0ull);
-        // io.ReadFull of this value fails when the bytes run out
-        const bool fail = neg || (live && incl > avail);
-        const uint64_t fm = __builtin_amdgcn_ballot_w64(fail);
+    int32_t cur[kPer], next[kPer];
+    load_lens(kPer * (uint32_t)lane, cur);
+    for (uint32_t base = 0; base < m; base += kPer * kWave) {
+        load_lens(base + kPer * (kWave + (uint32_t)lane), next);
+        const uint32_t i0 = base + kPer * (uint32_t)lane;
+        // this lane's lengths up to its first negative one
+        uint64_t inc[kPer], sum = 0;
+        uint32_t failk = kPer;  // first value of this lane that fails
+        bool neg = false;
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            if (i0 + k < m && failk == kPer) {
+                if (cur[k] < 0) {
+                    failk = k;
+                    neg = true;
+                } else {
+                    sum += (uint64_t)(uint32_t)cur[k];
+                }
+            }
+            inc[k] = sum;
+        }
+        const uint64_t excl = carry + wave_scan_u64(sum) - sum;
+        // io.ReadFull of a value fails when the bytes run out
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) {
+            if (i0 + k < m && k < failk && excl + inc[k] > avail) {
+                failk = k;
+                neg = false;
+            }
+        }
+        const uint64_t fm = __builtin_amdgcn_ballot_w64(failk < kPer);
         const uint32_t ok_lanes = fm ? (uint32_t)__builtin_ctzll(fm) : (uint32_t)kWave;
-        if (live && (uint32_t)lane < ok_lanes) area[i + 1] = (uint32_t)incl;
+        if ((uint32_t)lane <= ok_lanes) {
+            const uint32_t lim = (uint32_t)lane < ok_lanes ? kPer : failk;
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; ++k)
+                if (i0 + k < m && k < lim) area[i0 + k + 1] = (uint32_t)(excl + inc[k]);
+        }
         if (base == 0 && lane == 0) area[0] = 0;
         if (fm != 0ull) {
             // everything in front of the failing value is good
-            const uint64_t before = ok_lanes ? wave_readlane_u64(incl, ok_lanes - 1u) : carry;
+            const uint32_t fk = (uint32_t)__builtin_amdgcn_readlane((int)failk, (int)ok_lanes);
+            uint64_t in_front = 0;  // this lane's good lengths
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; ++k)
+                if (k < failk) in_front = inc[k];
+            const uint64_t mine = excl + in_front;
+            const uint64_t before = wave_readlane_u64(mine, ok_lanes);
             const bool was_neg = ((__builtin_amdgcn_ballot_w64(neg) >> ok_lanes) & 1ull) != 0ull;
-            done = base + ok_lanes;
+            done = base + kPer * ok_lanes + fk;
             status = was_neg ? PQ_BYTE_ARRAY_NEGATIVE_LEN : (before == avail ? PQ_EOF : PQ_UNEXPECTED_EOF);
             // a negative length panics before anything is read; a short read takes what is left
             res.consumed = lr.consumed + (was_neg ? before : avail);
             carry = before;
             break;
         }
-        carry = wave_last_u64(incl);
-        done = min(base + (uint32_t)kWave, m);
-        cur = next;
+        carry = wave_last_u64(excl + sum);
+        done = min(base + kPer * (uint32_t)kWave, m);
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k) cur[k] = next[k];
     }
     if (m == 0 && lane == 0) area[0] = 0;
     if (status == PQ_OK) {
@@ -321,6 +378,8 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const uint8_t *SUF = S + init_consumed;
+    uint8_t *prev = reinterpret_cast<uint8_t *>(window);  // the value in front of the batch (the lengths are done with the window)
+    bool prev_in_lds = false;
     uint32_t sc = 0;        // suffix bytes in front of this batch
     uint32_t prev_off = 0;  // offset of the value in front of this batch
     for (uint32_t base = 0; base < done; base += kWave) {
@@ -335,19 +394,43 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
         const uint32_t sincl = sc + wave_scan_u32(s);
         const uint32_t soff = sincl - s;
         const uint32_t maxlen = wave_max_u32(vlen);
+        const uint32_t nlive = min((uint32_t)kWave, done - base);
         if (maxlen <= kBaBatchMaxLen) {
             const uint32_t srcbase = soff - p;  // suffix-area offset of this value's position 0
             const uint64_t below = (2ull << lane) - 1ull;
-            for (uint32_t j = 0; j < maxlen; ++j) {
-                const uint64_t mk = __builtin_amdgcn_ballot_w64(p <= j) & below;
-                const bool has = mk != 0ull;
-                const int k = has ? 63 - __builtin_clzll(mk) : 0;
-                const uint32_t sb = (uint32_t)__shfl((int)srcbase, k);
-                const uint8_t *from = has ? SUF + (uint32_t)(sb + j) : data + prev_off + j;
-                if (j < vlen) data[o0 + j] = *from;
+            const bool is_last = (uint32_t)lane == nlive - 1u;
+            for (uint32_t j0 = 0; j0 < maxlen; j0 += 4u) {
+                uint8_t got[4];
+                // four positions' loads go out together
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t j = j0 + u;
+                    const uint64_t mk = __builtin_amdgcn_ballot_w64(p <= j) & below;
+                    const bool has = mk != 0ull;
+                    const int k = has ? 63 - __builtin_clzll(mk) : 0;
+                    const uint32_t sb = (uint32_t)__shfl((int)srcbase, k);
+                    uint8_t b = 0;
+                    if (j < vlen) {
+                        if (has)
+                            b = SUF[(uint32_t)(sb + j)];
+                        else if (prev_in_lds)
+                            b = prev[j];
+                        else
+                            b = data[prev_off + j];
+                    }
+                    got[u] = b;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t j = j0 + u;
+                    if (j < vlen) {
+                        data[o0 + j] = got[u];
+                        if (is_last) prev[j] = got[u];
+                    }
+                }
             }
+            prev_in_lds = true;
         } else {
-            const uint32_t nlive = min((uint32_t)kWave, done - base);
             for (uint32_t l = 0; l < nlive; ++l) {
                 const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)l);
                 const uint32_t vl = (uint32_t)__builtin_amdgcn_readlane((int)vlen, (int)l);
@@ -360,10 +443,11 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
                 }
                 for (uint32_t j = (uint32_t)lane; j < vl - pl; j += kWave) data[ol + pl + j] = SUF[sl + j];
             }
+            workgroup_fence();
+            prev_in_lds = false;
         }
-        prev_off = (uint32_t)__builtin_amdgcn_readlane((int)o0, 63);
+        prev_off = (uint32_t)__builtin_amdgcn_readlane((int)o0, (int)(nlive - 1u));
         sc = wave_last_u32(sincl);
-        workgroup_fence();
     }
     return res;
 }

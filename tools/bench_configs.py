@@ -10,6 +10,7 @@ device-resident, HIP-event timed.  Prints one JSON object per configuration.
   P   PLAIN int64 / int32 values, BOOLEAN PLAIN bits, BOOLEAN RLE runs
   B   DELTA_LENGTH_BYTE_ARRAY (random 4..20-byte values) and DELTA_BYTE_ARRAY (sorted words, shared prefixes):
       value bytes + uint32 offsets out
+  W   page-header walk of 64 column chunks x 800 V1 pages (headers with statistics, 20 KB page bodies)
   L   level post-processing over 100 M slots: column entries (validity, offsets, returned definition
       levels) of a REPEATED and of an OPTIONAL column, PackedArray bytes of the levels
 """
@@ -286,6 +287,44 @@ def bench_byte_array(ctx, stream, pages, n, front):
     plan.close()
 
 
+def bench_walk(ctx, stream, n_chunks, pages_per_chunk, body):
+    rng = np.random.default_rng(9)
+    heads = [np.frombuffer(synth.page_header(0, body, body, data=(20000, 8, 3, 3, synth.statistics(rng))), dtype=np.uint8)
+             for _ in range(16)]
+    chunk_bytes = sum(heads[k % 16].size + body for k in range(pages_per_chunk))
+    stride = (chunk_bytes + 255) // 256 * 256
+    src = np.zeros(n_chunks * stride + 64, dtype=np.uint8)
+    for c in range(n_chunks):
+        pos = c * stride
+        for k in range(pages_per_chunk):
+            h = heads[k % 16]
+            src[pos: pos + h.size] = h
+            pos += h.size + body
+    chunks = np.zeros(n_chunks, dtype=capi.CHUNK_DTYPE)
+    chunks["src_off"] = np.arange(n_chunks, dtype=np.uint64) * np.uint64(stride)
+    chunks["src_len"] = chunk_bytes
+    chunks["total_compressed_size"] = chunk_bytes
+    chunks["data_page_offset"] = 4
+    chunks["physical_type"], chunks["type_length"] = 1, -1
+    chunks["info_first"] = np.arange(n_chunks, dtype=np.uint32) * pages_per_chunk
+    chunks["info_cap"] = pages_per_chunk
+    t_src = torch.from_numpy(src).to(DEV)
+    t_infos = torch.zeros(n_chunks * pages_per_chunk * capi.PAGE_INFO_DTYPE.itemsize, dtype=torch.uint8, device=DEV)
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        res = ctx.walk_chunks_dev(t_src.data_ptr(), src.size, chunks, t_infos.data_ptr(), n_chunks * pages_per_chunk)
+        times.append(time.perf_counter() - t0)     # the call waits for the stream: upload, kernel, results
+    assert (res["status"] == 0).all() and (res["n_pages"] == pages_per_chunk).all()
+    infos = t_infos.cpu().numpy().view(capi.PAGE_INFO_DTYPE)
+    assert (infos["num_values"] == 20000).all() and (infos["compressed_size"] == body).all()
+    t = float(np.median(times[1:]))
+    print(json.dumps({"config": "W page-header walk", "chunks": n_chunks, "pages_per_chunk": pages_per_chunk,
+                      "ms_per_call": round(t * 1e3, 3), "pages_per_s": round(n_chunks * pages_per_chunk / t),
+                      "us_per_page_of_a_chunk": round(t * 1e6 / pages_per_chunk, 3),
+                      "header_bytes": int(np.mean([h.size for h in heads]))}), flush=True)
+
+
 def bench_levels(ctx, stream, n):
     g = torch.Generator(device=DEV)
     g.manual_seed(7)
@@ -344,6 +383,9 @@ def main():
     if want("bytes"):
         bench_byte_array(ctx, stream, args.pages, 20000, False)
         bench_byte_array(ctx, stream, args.pages, 20000, True)
+    if want("walk"):
+        bench_walk(ctx, stream, 64, 800, 20000)
+        bench_walk(ctx, stream, 1024, 100, 20000)
     if want("levels"):
         bench_levels(ctx, stream, 100_000_000)
     print("elapsed %.1fs" % (time.time() - t0), file=sys.stderr)
