@@ -15,10 +15,17 @@
  * types/float_test.go, types/double_test.go).
  * The reference has no tests for types.DictDecoder, layout.decodePackedArray,
  * the V1/V2 page section order, multi-block delta streams, multi-run hybrid
- * decoding, the int32 / int64 PLAIN decoders, the BOOLEAN decoders or
- * ColumnStore.Get: for those the oracle follows the reference source line by
- * line and its parity is UNPINNED by any reference fixture.  The Go toolchain is not
- * available, so the reference itself was never executed.
+ * decoding, the int32 / int64 PLAIN decoders, the BOOLEAN decoders,
+ * ColumnStore.Get, the two byte-array decoders of types/byte-array.go or the
+ * page-header loop of layout/chunk.go: for those the oracle follows the
+ * reference source line by line and its parity is UNPINNED by any reference
+ * fixture.  The Go toolchain is not available, so the reference itself was
+ * never executed.  The Thrift compact reader behind the page-header loop is a
+ * dependency the reference does not vendor; it is restated from the published
+ * encoding (see pqo_walk_chunk).  What the tests add besides: Parquet files
+ * written by pyarrow, read back through the oracle and compared with what
+ * pyarrow reads (tests/test_walk_oracle.py) - an independent check of the wire
+ * formats, not of the reference's quirks.
  */
 #ifndef PQ_ORACLE_H
 #define PQ_ORACLE_H

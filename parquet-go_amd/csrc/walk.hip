@@ -35,8 +35,10 @@ struct WalkReader {
     uint32_t *frames;   // 2 * kWkDepth words: the skip stack
     const uint8_t *S;   // chunk byte 0
     int64_t len;
-    int64_t c0;         // stream offset of the window (INT64_MIN: nothing staged)
+    int64_t c0;         // stream offset of the window (far below zero: nothing staged)
     int64_t pos;
+    uint64_t buf;       // the next `have` bytes of the stream, lowest byte first
+    uint32_t have;
     int lane;
 };
 
@@ -51,12 +53,29 @@ __device__ __forceinline__ void wk_stage(WalkReader &r)
     wave_sync();
 }
 
+// Eight stream bytes from pos on into the register buffer: a header is parsed from registers,
+// one trip to LDS per eight bytes instead of one per byte.
+__device__ __forceinline__ void wk_refill(WalkReader &r)
+{
+    if (r.pos < r.c0 || r.pos + 8 > r.c0 + kWkWin) wk_stage(r);  // a window starts at most 15 bytes below pos
+    const uint32_t o = (uint32_t)(r.pos - r.c0);
+    const uint32_t *w = r.lds + (o >> 2);
+    const uint32_t sh = (o & 3u) * 8u;
+    // every lane holds the same bytes: saying so keeps the whole parse on the scalar unit
+    const uint32_t lo = uni(__builtin_amdgcn_alignbit(w[1], w[0], sh));
+    const uint32_t hi = uni(__builtin_amdgcn_alignbit(w[2], w[1], sh));
+    r.buf = ((uint64_t)hi << 32) | lo;
+    r.have = 8;
+}
+
 // ReadByte: false when the source is exhausted
 __device__ __forceinline__ bool wk_byte(WalkReader &r, uint32_t *b)
 {
     if (r.pos >= r.len) return false;
-    if (r.pos < r.c0 || r.pos >= r.c0 + kWkWin) wk_stage(r);
-    *b = reinterpret_cast<const uint8_t *>(r.lds)[r.pos - r.c0];
+    if (r.have == 0) wk_refill(r);
+    *b = (uint32_t)r.buf & 255u;
+    r.buf >>= 8;
+    r.have -= 1;
     r.pos += 1;
     return true;
 }
@@ -64,6 +83,7 @@ __device__ __forceinline__ bool wk_byte(WalkReader &r, uint32_t *b)
 // io.ReadFull of n bytes nobody looks at
 __device__ __forceinline__ bool wk_advance(WalkReader &r, uint64_t n)
 {
+    r.have = 0;
     if ((uint64_t)(r.len - r.pos) < n) {
         r.pos = r.len;
         return false;
@@ -182,8 +202,8 @@ __device__ __forceinline__ bool wk_skip(WalkReader &r, uint32_t type)
         // the next value to step over
         while (true) {
             if (sp == 0) return true;
-            const uint32_t f = r.frames[2 * (sp - 1)];
-            const uint32_t x = r.frames[2 * (sp - 1) + 1];
+            const uint32_t f = uni(r.frames[2 * (sp - 1)]);
+            const uint32_t x = uni(r.frames[2 * (sp - 1) + 1]);
             if ((f & 255u) == F_STRUCT) {
                 int32_t id = 0, last = (int32_t)x;
                 if (!wk_field(r, &type, &id, &last)) return false;
@@ -320,6 +340,7 @@ __device__ __forceinline__ int32_t wk_block(WalkReader &r, uint32_t codec, int32
     const uint64_t want = compressed > 0 ? (uint64_t)compressed : 0ull;  // io.LimitReader(in, negative) reads nothing
     const uint64_t got = want < left ? want : left;
     r.pos += (int64_t)got;
+    r.have = 0;
     if ((int64_t)got != (int64_t)compressed) return PQ_WALK_BLOCK_SIZE;
     if (codec == 0 && compressed != uncompressed) return PQ_WALK_UNCOMPRESSED_SIZE;
     return PQ_OK;
@@ -330,9 +351,9 @@ __global__ __launch_bounds__(kWkWaves *kWave) void walk_chunks_kernel(const pq_c
                                                                      pq_page_info *__restrict__ infos,
                                                                      pq_chunk_result *__restrict__ results)
 {
-    __shared__ uint32_t s_win[kWkWaves][kWkWin / 4];
+    __shared__ uint32_t s_win[kWkWaves][kWkWin / 4 + 4];
     __shared__ uint32_t s_frames[kWkWaves][2 * kWkDepth];
-    const int wave = (int)(threadIdx.x / kWave), lane = (int)(threadIdx.x % kWave);
+    const int wave = (int)uni(threadIdx.x / kWave), lane = (int)(threadIdx.x % kWave);
     const uint32_t ci = blockIdx.x * kWkWaves + (uint32_t)wave;
     if (ci >= n_chunks) return;
     const pq_chunk_desc c = chunks[ci];
@@ -344,6 +365,8 @@ __global__ __launch_bounds__(kWkWaves *kWave) void walk_chunks_kernel(const pq_c
     r.len = (int64_t)c.src_len;
     r.c0 = INT64_MIN / 2;
     r.pos = 0;
+    r.buf = 0;
+    r.have = 0;
     r.lane = lane;
 
     const int64_t start = c.has_dictionary_page_offset ? c.dictionary_page_offset : c.data_page_offset;
@@ -442,6 +465,7 @@ __global__ __launch_bounds__(kWkWaves *kWave) void walk_chunks_kernel(const pq_c
             }
             count += target - r.pos;
             r.pos = target > r.len ? r.len : target;
+            r.have = 0;
         }
     }
     if (lane == 0) {

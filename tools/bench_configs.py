@@ -287,9 +287,10 @@ def bench_byte_array(ctx, stream, pages, n, front):
     plan.close()
 
 
-def bench_walk(ctx, stream, n_chunks, pages_per_chunk, body):
+def bench_walk(ctx, stream, n_chunks, pages_per_chunk, body, with_statistics=True):
     rng = np.random.default_rng(9)
-    heads = [np.frombuffer(synth.page_header(0, body, body, data=(20000, 8, 3, 3, synth.statistics(rng))), dtype=np.uint8)
+    heads = [np.frombuffer(synth.page_header(0, body, body, data=(20000, 8, 3, 3, synth.statistics(rng))
+                                             if with_statistics else (20000, 8, 3, 3)), dtype=np.uint8)
              for _ in range(16)]
     chunk_bytes = sum(heads[k % 16].size + body for k in range(pages_per_chunk))
     stride = (chunk_bytes + 255) // 256 * 256
@@ -386,6 +387,7 @@ def main():
     if want("walk"):
         bench_walk(ctx, stream, 64, 800, 20000)
         bench_walk(ctx, stream, 1024, 100, 20000)
+        bench_walk(ctx, stream, 64, 800, 20000, with_statistics=False)
     if want("levels"):
         bench_levels(ctx, stream, 100_000_000)
     print("elapsed %.1fs" % (time.time() - t0), file=sys.stderr)
