@@ -748,6 +748,67 @@ inline ChunkData readPageData(Device &dev, const ColumnSpec &col, const std::vec
     return out;
 }
 
+// ---- layout.ChunkReader.readPages (layout/chunk.go:129-217) ---------------------------------------
+// The page headers of column chunks, all chunks of a row group in one device call.  ColumnChunkMeta
+// carries what the loop takes from parquet.ColumnMetaData and schema.Column.
+struct ColumnChunkMeta {
+    int64_t TotalCompressedSize = 0;
+    int64_t DataPageOffset = 0;
+    bool hasDictionaryPageOffset = false;
+    int64_t DictionaryPageOffset = 0;
+    uint32_t Type = 1;          // parquet.Type
+    int32_t TypeLength = -1;    // < 0: nil
+    uint16_t MaxRepetitionLevel = 0, MaxDefinitionLevel = 0;
+    uint32_t Codec = 0;         // parquet.CompressionCodec
+};
+
+struct ChunkPages {
+    std::vector<pq_page_info> pages;  // in file order, the dictionary page included
+    int64_t count = 0;                // offsetReader.Count()
+    Error err;                        // the first error; pages in front of it are kept
+};
+
+// file: the bytes of the source from offset fileOffset on (a whole file: fileOffset 0).  Each
+// chunk is read from its DictionaryPageOffset when it has one, else from DataPageOffset (:58-61).
+inline std::vector<ChunkPages> readPages(Device &dev, const uint8_t *file, size_t fileLen, int64_t fileOffset,
+                                         const std::vector<ColumnChunkMeta> &chunks, uint32_t maxPagesPerChunk = 4096)
+{
+    std::vector<pq_chunk_desc> descs(chunks.size());
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        const ColumnChunkMeta &m = chunks[i];
+        pq_chunk_desc &d = descs[i];
+        std::memset(&d, 0, sizeof d);
+        const int64_t start = (m.hasDictionaryPageOffset ? m.DictionaryPageOffset : m.DataPageOffset) - fileOffset;
+        if (start < 0 || (uint64_t)start > fileLen) throw std::runtime_error("readPages: chunk outside the source");
+        d.src_off = (uint64_t)start;
+        d.src_len = fileLen - (uint64_t)start;
+        d.total_compressed_size = m.TotalCompressedSize;
+        d.data_page_offset = m.DataPageOffset;
+        d.dictionary_page_offset = m.DictionaryPageOffset;
+        d.has_dictionary_page_offset = m.hasDictionaryPageOffset ? 1u : 0u;
+        d.physical_type = m.Type;
+        d.type_length = m.TypeLength;
+        d.max_rep = m.MaxRepetitionLevel;
+        d.max_def = m.MaxDefinitionLevel;
+        d.codec = m.Codec;
+        d.info_first = (uint32_t)(i * maxPagesPerChunk);
+        d.info_cap = maxPagesPerChunk;
+    }
+    std::vector<pq_page_info> infos(chunks.size() * (size_t)maxPagesPerChunk);
+    std::vector<pq_chunk_result> res(chunks.size());
+    check_library(pq_walk_chunks(dev.ctx(), file, fileLen, descs.data(), descs.size(), infos.data(), infos.size(),
+                                 res.data()),
+                  "pq_walk_chunks");
+    std::vector<ChunkPages> out(chunks.size());
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        if (res[i].status >= PQ_ERR_BAD_ARGUMENT) check_library(res[i].status, "readPages: more pages than maxPagesPerChunk");
+        out[i].pages.assign(infos.begin() + i * maxPagesPerChunk, infos.begin() + i * maxPagesPerChunk + res[i].n_pages);
+        out[i].count = res[i].count;
+        out[i].err = Error(res[i].status);
+    }
+    return out;
+}
+
 // ---- level post-processing ----------------------------------------------------------------
 // packLevels: the PackedArray the reference would hold after appending these levels one by one
 // (file-reader.go:285-296), packed on the device.

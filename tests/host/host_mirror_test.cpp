@@ -830,6 +830,127 @@ static void TestByteArrayDecoders(Device &dev)
     }
 }
 
+// ---- ChunkReader.readPages (no reference test; headers written by hand in the compact protocol,
+//      checked field by field and against the oracle) -------------------------------------------------
+static void put_varint(std::vector<uint8_t> &o, uint64_t v)
+{
+    while (v >= 0x80) {
+        o.push_back((uint8_t)(v | 0x80));
+        v >>= 7;
+    }
+    o.push_back((uint8_t)v);
+}
+static void put_i32(std::vector<uint8_t> &o, int delta, int32_t v)  // field header (short form) + zig-zag value
+{
+    o.push_back((uint8_t)(delta << 4 | 5));
+    put_varint(o, (uint32_t)((v << 1) ^ (v >> 31)));
+}
+// PageHeader{type, uncompressed, compressed, data_page_header{num_values, encoding, RLE, RLE}} or a dictionary header
+static std::vector<uint8_t> page_header_bytes(int32_t type, int32_t size, int32_t num_values, int32_t encoding)
+{
+    std::vector<uint8_t> o;
+    put_i32(o, 1, type);
+    put_i32(o, 1, size);
+    put_i32(o, 1, size);
+    if (type == 0) {
+        o.push_back(2 << 4 | 12);  // field 5: struct
+        put_i32(o, 1, num_values);
+        put_i32(o, 1, encoding);
+        put_i32(o, 1, 3);
+        put_i32(o, 1, 3);
+        o.push_back(0);
+    } else {
+        o.push_back(4 << 4 | 12);  // field 7: struct
+        put_i32(o, 1, num_values);
+        put_i32(o, 1, encoding);
+        o.push_back(0);
+    }
+    o.push_back(0);
+    return o;
+}
+
+static void TestReadPages(Device &dev)
+{
+    // a file with two chunks: [dictionary, data, data] and [data], some bytes in front and between
+    std::vector<uint8_t> file(37, 0xee);
+    std::vector<ColumnChunkMeta> metas(2);
+    auto add_page = [&](int32_t type, int32_t size, int32_t nv, int32_t enc) {
+        std::vector<uint8_t> h = page_header_bytes(type, size, nv, enc);
+        file.insert(file.end(), h.begin(), h.end());
+        file.insert(file.end(), (size_t)size, (uint8_t)0x11);
+    };
+    metas[0].hasDictionaryPageOffset = true;
+    metas[0].DictionaryPageOffset = (int64_t)file.size();
+    add_page(2, 40, 10, 0);
+    metas[0].DataPageOffset = (int64_t)file.size();
+    add_page(0, 300, 200, 8);
+    add_page(0, 123, 77, 2);
+    metas[0].TotalCompressedSize = (int64_t)file.size() - metas[0].DictionaryPageOffset;
+    file.insert(file.end(), 5, 0xee);
+    metas[1].DataPageOffset = (int64_t)file.size();
+    metas[1].Type = 2;
+    add_page(0, 8000, 1000, 5);
+    metas[1].TotalCompressedSize = (int64_t)file.size() - metas[1].DataPageOffset;
+
+    std::vector<ChunkPages> got = readPages(dev, file.data(), file.size(), 0, metas);
+    CHECK_EQ(got.size(), 2);
+    CHECK(!got[0].err);
+    CHECK(!got[1].err);
+    CHECK_EQ(got[0].pages.size(), 3);
+    CHECK_EQ(got[1].pages.size(), 1);
+    CHECK_EQ(got[0].count, metas[0].TotalCompressedSize);
+    CHECK_EQ(got[1].count, metas[1].TotalCompressedSize);
+    CHECK_EQ(got[0].pages[0].type, 2);
+    CHECK_EQ(got[0].pages[0].num_values, 10);
+    CHECK_EQ(got[0].pages[1].num_values, 200);
+    CHECK_EQ(got[0].pages[1].encoding, 8);
+    CHECK_EQ(got[0].pages[2].compressed_size, 123);
+    CHECK_EQ(got[1].pages[0].uncompressed_size, 8000);
+    CHECK_EQ(got[1].pages[0].def_encoding, 3);
+    // the same chunks through the oracle
+    for (size_t c = 0; c < 2; ++c) {
+        pqo_chunk_in in;
+        std::memset(&in, 0, sizeof in);
+        const int64_t start = metas[c].hasDictionaryPageOffset ? metas[c].DictionaryPageOffset : metas[c].DataPageOffset;
+        in.src = file.data() + start;
+        in.src_len = file.size() - (size_t)start;
+        in.total_compressed_size = metas[c].TotalCompressedSize;
+        in.data_page_offset = metas[c].DataPageOffset;
+        in.dictionary_page_offset = metas[c].DictionaryPageOffset;
+        in.has_dictionary_page_offset = metas[c].hasDictionaryPageOffset;
+        in.physical_type = metas[c].Type;
+        in.type_length = -1;
+        std::vector<pqo_page_info> want(16);
+        uint32_t n = 0;
+        int64_t count = 0;
+        CHECK_EQ(pqo_walk_chunk(&in, want.data(), 16, &n, &count), 0);
+        CHECK_EQ(n, got[c].pages.size());
+        CHECK_EQ(count, got[c].count);
+        static_assert(sizeof(pqo_page_info) == sizeof(pq_page_info), "same record layout");
+        CHECK(std::memcmp(want.data(), got[c].pages.data(), n * sizeof(pq_page_info)) == 0);
+    }
+    // a second dictionary page, and a chunk cut in the middle of a block
+    std::vector<ColumnChunkMeta> bad(2);
+    std::vector<uint8_t> f2;
+    auto add2 = [&](int32_t type, int32_t size, int32_t nv, int32_t enc, size_t body) {
+        std::vector<uint8_t> h = page_header_bytes(type, size, nv, enc);
+        f2.insert(f2.end(), h.begin(), h.end());
+        f2.insert(f2.end(), body, (uint8_t)0);
+    };
+    bad[0].DataPageOffset = 0;
+    add2(2, 16, 4, 0, 16);
+    add2(2, 16, 4, 0, 16);
+    bad[0].TotalCompressedSize = (int64_t)f2.size();
+    bad[1].DataPageOffset = (int64_t)f2.size();
+    add2(0, 100, 5, 0, 60);
+    bad[1].TotalCompressedSize = 200;
+    std::vector<ChunkPages> r2 = readPages(dev, f2.data(), f2.size(), 0, bad);
+    CHECK(r2[0].err.is(PQ_WALK_SECOND_DICTIONARY));
+    CHECK_EQ(r2[0].pages.size(), 1);
+    CHECK(r2[1].err.is(PQ_WALK_BLOCK_SIZE));
+    CHECK_EQ(r2[1].pages.size(), 0);
+}
+
 int main()
 {
     Device dev(0);
@@ -849,6 +970,7 @@ int main()
         {"TestDecodePackedArray", [&] { TestDecodePackedArray(dev); }},
         {"TestDataPages", [&] { TestDataPages(dev); }},
         {"TestByteArrayDecoders", [&] { TestByteArrayDecoders(dev); }},
+        {"TestReadPages", [&] { TestReadPages(dev); }},
     };
     for (auto &t : tests) {
         int before = g_failed;
