@@ -423,7 +423,8 @@ def test_delta_random_vs_oracle(ctx, bits):
 
 @pytest.mark.parametrize("bits", [32, 64])
 def test_delta_truncated_at_every_byte(ctx, bits):
-    """Error classes and counts when the stream ends anywhere (a7-iii/iv)."""
+    """Error classes and counts when the stream ends anywhere (the group fetched at position N - 1 and
+    io.ReadFull of a cut group: encoding/delta-binary-packed-decoder.go:103,112)."""
     rng = _rng(30 + bits)
     kind = K.KIND_DELTA32 if bits == 32 else K.KIND_DELTA64
     dt = np.int32 if bits == 32 else np.int64

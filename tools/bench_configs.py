@@ -237,8 +237,9 @@ def bench_plain(ctx, stream, pages, n, kind, es, label):
     plan.close()
 
 
-def bench_byte_array(ctx, stream, pages, n, front):
-    """front: DELTA_BYTE_ARRAY over sorted 3..13-letter words; else DELTA_LENGTH_BYTE_ARRAY over random bytes."""
+def bench_byte_array(ctx, stream, pages, n, front, pull=None):
+    """front: DELTA_BYTE_ARRAY over sorted 3..13-letter words; else DELTA_LENGTH_BYTE_ARRAY over random bytes.
+    pull: values asked of each page (default all); 0 times Init alone, i.e. the two length streams."""
     rng = np.random.default_rng(8)
     distinct = min(pages, 8)
     streams, flats, offs_want = [], [], []
@@ -261,7 +262,7 @@ def bench_byte_array(ctx, stream, pages, n, front):
     area = (area + 15) // 16 * 16
     descs = np.zeros(pages, dtype=capi.DESC_DTYPE)
     descs["kind"] = capi.KIND_DELTA_BA if front else capi.KIND_DELTA_LENGTH_BA
-    descs["src_off"], descs["src_len"], descs["n_values"] = offs, lens, n
+    descs["src_off"], descs["src_len"], descs["n_values"] = offs, lens, n if pull is None else pull
     descs["dst_off"] = np.arange(pages, dtype=np.uint64) * np.uint64(room + area)
     descs["dict_off"] = descs["dst_off"] + np.uint64(room)
     descs["dict_len"] = n
@@ -272,6 +273,11 @@ def bench_byte_array(ctx, stream, pages, n, front):
     fn = lambda: plan.run(t_src.data_ptr(), src.size, t_out.data_ptr(), t_out.numel())
     t = timed(fn, stream, steps=6, warmup=1)
     res = plan.results()
+    if pull is not None:
+        report("B %s, Init + %d values per page" % ("DELTA_BYTE_ARRAY" if front else "DELTA_LENGTH_BYTE_ARRAY", pull),
+               int(lens.sum()), 0, t, {"pages": pages})
+        plan.close()
+        return
     assert (res["status"] == 0).all() and (res["n_decoded"] == n).all(), res[:4]
     got = t_out.cpu().numpy().reshape(pages, room + area)
     out_bytes = 0
@@ -384,6 +390,9 @@ def main():
     if want("bytes"):
         bench_byte_array(ctx, stream, args.pages, 20000, False)
         bench_byte_array(ctx, stream, args.pages, 20000, True)
+    if want("bytes_init"):
+        bench_byte_array(ctx, stream, args.pages, 20000, False, pull=0)
+        bench_byte_array(ctx, stream, args.pages, 20000, True, pull=0)
     if want("walk"):
         bench_walk(ctx, stream, 64, 800, 20000)
         bench_walk(ctx, stream, 1024, 100, 20000)
