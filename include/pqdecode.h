@@ -164,6 +164,9 @@ int pq_bitunpack64(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, size_
 #define PQ_FLAG_LEVELS_CONST 2u    /* LEVELS: ConstDecoder(0) (layout/chunk.go:111-124) */
 #define PQ_FLAG_NO_INIT 4u         /* HYBRID/LEVELS: decoder never initialised
                                       (zero-length V2 level section, layout/page-v2.go:92-102) */
+#define PQ_FLAG_NO_LEVEL_OUTPUT 8u /* pages of a column with max_rep == 0: both level decoders are
+                                      ConstDecoder(0) (layout/chunk.go:111-124) and every level is 0;
+                                      do not write the zeros (rep_off / def_off are not used) */
 
 typedef struct pq_page_desc {
     uint32_t kind;        /* PQ_KIND_* */

@@ -22,7 +22,7 @@ ERR_BAD_ARGUMENT, ERR_HIP, ERR_NO_DEVICE, ERR_OUT_OF_RANGE = 100, 101, 102, 103
 KIND_HYBRID, KIND_DICT, KIND_LEVELS, KIND_DELTA32, KIND_DELTA64, KIND_PAGE_V1, KIND_PAGE_V2 = range(1, 8)
 KIND_PLAIN, KIND_BOOL_PLAIN, KIND_BOOL_RLE, KIND_DELTA_LENGTH_BA, KIND_DELTA_BA = 8, 9, 10, 11, 12
 BYTE_ARRAY_NEGATIVE_LEN, BYTE_ARRAY_COUNT_MISMATCH, BYTE_ARRAY_INVALID_PREFIX = 16, 17, 18
-FLAG_LENGTH_PREFIXED, FLAG_LEVELS_CONST, FLAG_NO_INIT = 1, 2, 4
+FLAG_LENGTH_PREFIXED, FLAG_LEVELS_CONST, FLAG_NO_INIT, FLAG_NO_LEVEL_OUTPUT = 1, 2, 4, 8
 OPT_DELTA_WAVE_MIN_PAGES = 1
 OPT_HYBRID_WAVE_MIN_PAGES = 2
 

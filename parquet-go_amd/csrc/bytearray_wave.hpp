@@ -109,12 +109,12 @@ struct ByteArrayLens {
 __device__ __forceinline__ ByteArrayLens ba_lengths_wave(uint32_t *window, const uint8_t *S, int64_t len, uint32_t cap,
                                                          uint32_t *area, int lane)
 {
-    WaveDeltaResult lr = delta_wave<uint32_t>(window, S, len, 0x7fffffffu, area, lane, cap);
+    WaveDeltaResult lr = delta_wave<uint32_t, false>(window, S, len, 0x7fffffffu, area, lane, cap);
     // More lengths declared than the area holds: decode as many as fit.  A stream that fails
     // before that many ends Init with the reference's own error; only one that really yields
     // them all is refused for want of room.
     const bool over = lr.status == kOverCap;
-    if (over) lr = delta_wave<uint32_t>(window, S, len, cap, area, lane);
+    if (over) lr = delta_wave<uint32_t, false>(window, S, len, cap, area, lane);
     if (lr.status == kNeedGeneric) {
         // a block layout other than 128 / 4: one lane decodes the lengths
         uint32_t total = 0;

@@ -363,9 +363,11 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
             plan->values_need = std::max(plan->values_need,
                                          d.dict_off + (uint64_t)4 * ((uint64_t)(front ? 2 : 1) * d.dict_len + 1));
         }
-        if (page || d.kind == PQ_KIND_LEVELS)
+        // a page of a flat column that keeps its constant-zero levels to itself needs no level room
+        const bool no_levels = page && d.max_rep == 0 && (d.flags & PQ_FLAG_NO_LEVEL_OUTPUT) != 0;
+        if ((page && !no_levels) || d.kind == PQ_KIND_LEVELS)
             plan->levels_need = std::max(plan->levels_need, d.def_off + (uint64_t)4 * d.n_values);
-        if (page) plan->levels_need = std::max(plan->levels_need, d.rep_off + (uint64_t)4 * d.n_values);
+        if (page && !no_levels) plan->levels_need = std::max(plan->levels_need, d.rep_off + (uint64_t)4 * d.n_values);
         if (d.kind == PQ_KIND_DICT || (page && d.value_kind == PQ_KIND_DICT)) {
             const uint64_t db = (uint64_t)d.dict_len * d.elem_size;
             plan->dict_need = std::max(plan->dict_need, d.dict_off + db);
@@ -858,10 +860,15 @@ int pq_chunk_page_descs(const pq_chunk_desc *chunk, const pq_page_info *infos, u
             d.dst_off = (layout->values_off + vs - 1) / vs * vs;
             layout->values_off = d.dst_off + value_bytes;
         }
-        layout->levels_off = (layout->levels_off + 3) / 4 * 4;
-        d.rep_off = layout->levels_off;
-        d.def_off = d.rep_off + 4ull * d.n_values;
-        layout->levels_off = d.def_off + 4ull * d.n_values;
+        if (chunk->max_rep == 0) {
+            // both level decoders are ConstDecoder(0) (layout/chunk.go:111-124): nothing worth writing
+            d.flags |= PQ_FLAG_NO_LEVEL_OUTPUT;
+        } else {
+            layout->levels_off = (layout->levels_off + 3) / 4 * 4;
+            d.rep_off = layout->levels_off;
+            d.def_off = d.rep_off + 4ull * d.n_values;
+            layout->levels_off = d.def_off + 4ull * d.n_values;
+        }
         descs[out++] = d;
     }
     *n_descs = out;

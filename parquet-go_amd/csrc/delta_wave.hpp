@@ -1,5 +1,7 @@
-// delta_wave.hpp — one WAVE per page DELTA_BINARY_PACKED decoder for the layout every
-// mainstream writer emits: 128-value blocks of 4 miniblocks (32 values each).
+// delta_wave.hpp — one WAVE per page DELTA_BINARY_PACKED decoder for the layouts the
+// mainstream writers emit: 128-value blocks of 4 miniblocks (32 values each; the reference's
+// own encoders, parquet-mr, Arrow's INT32) and 256-value blocks of 4 miniblocks (64 values
+// each; Arrow's INT64).  A tile is 128 values either way: a block, or half of one.
 //
 // Same value sequence as delta_stream.hpp (reference:
 // encoding/delta-binary-packed-decoder.go:29-170,213-225,289-301), organised so that
@@ -90,8 +92,28 @@ struct WaveState {
     uint32_t finished;
     uint32_t init_failed;
     uint32_t last_widths; // widths of the block that holds the last group read
-    uint32_t last_group;  // index of that group inside its block (0..15)
+    uint32_t last_group;  // index of that group inside its block (0..15, or 0..31 for 256-value blocks)
+    uint32_t lg;          // log2 of the values per miniblock: 5 (blocks of 128) or 6 (blocks of 256)
 };
+
+// The block the walk is inside of (all wave-uniform).  A tile is always 128 values: a whole block
+// of the 128 / 4 layout, half a block of the 256 / 4 layout (the int64 layout of Arrow's writer);
+// the second half reuses the header its first half parsed.
+struct WaveBlock {
+    uint32_t half;    // 256 / 4 only: 1 = the next tile is the second half of this block
+    uint32_t wd;      // the block's 4 miniblock widths
+    uint32_t md_raw;  // 1: minDelta is still its raw varint (hdr_lo, vl), else md holds it
+    uint32_t hdr_lo, vl;
+    uint64_t md;
+};
+
+// minDelta from a raw varint of 1..4 bytes (scalar twin of wave_expand_min_delta).
+__device__ __forceinline__ int64_t wave_raw_min_delta(uint32_t hdr_lo, uint32_t vl)
+{
+    const uint32_t v = hdr_lo & (0xffffffffu >> (32u - 8u * vl));
+    const uint32_t x = (v & 0x7fu) | ((v >> 1) & 0x3f80u) | ((v >> 2) & 0x1fc000u) | ((v >> 3) & 0xfe00000u);
+    return (int64_t)((int32_t)(x >> 1) ^ -(int32_t)(x & 1u));
+}
 
 __device__ __forceinline__ WaveTile wave_tile_none()
 {
@@ -111,8 +133,9 @@ __device__ __forceinline__ WaveTile wave_tile_none()
 // Walk one block header at st.pos with every check of the reference's reader:
 // taken for a page's last block, for blocks cut short by the end of the stream
 // and for malformed headers.  B = LDS window bytes, c0 = its stream offset.
-template <typename UT>
-__device__ __forceinline__ WaveTile wave_walk_slow(WaveState<UT> &st, const uint8_t *B, int64_t c0, int64_t len)
+template <typename UT, uint32_t LG>
+__device__ __forceinline__ WaveTile wave_walk_slow(WaveState<UT> &st, WaveBlock &blk, const uint8_t *B, int64_t c0,
+                                                   int64_t len)
 {
     WaveTile t = wave_tile_none();
     if (st.finished) return t;
@@ -122,70 +145,81 @@ __device__ __forceinline__ WaveTile wave_walk_slow(WaveState<UT> &st, const uint
         st.n_ok = st.need;
         return t;
     }
+    constexpr uint32_t lg = LG;
+    constexpr uint32_t G = 1u << (lg - 3u);    // groups per miniblock: 4 or 8
+    constexpr uint32_t MT = 1u << (7u - lg);   // miniblocks per tile: 4 or 2
+    const uint32_t half = lg == 5u ? 0u : blk.half;
     int64_t pos = st.pos;
-    uint64_t u;
-    int hs = read_uvarint(B, c0, len, &pos, &u);
     int64_t md = 0;
-    if (hs == PQ_OK) {
-        md = unzigzag(u);
-        if (sizeof(UT) == 4 && (md > 2147483647ll || md < -2147483648ll)) hs = PQ_INT32_OUT_OF_RANGE;
-    }
     uint32_t wd = 0;
-    if (hs == PQ_OK) {
-        const int64_t rem = len - pos;
-        if (rem <= 0) hs = PQ_EOF;
-        else if (rem < 4) hs = PQ_UNEXPECTED_EOF;
-        else {
-            const uint32_t o = (uint32_t)(pos - c0);
-            wd = (uint32_t)B[o] | ((uint32_t)B[o + 1] << 8) | ((uint32_t)B[o + 2] << 16) | ((uint32_t)B[o + 3] << 24);
-            pos += 4;
-            // any byte > 32 ?  (byte + 95 carries into bit 7, or bit 7 already set)
-            if ((((wd & 0x7f7f7f7fu) + 0x5f5f5f5fu) | wd) & 0x80808080u) hs = PQ_INVALID_MINIBLOCK_WIDTH;
+    if (half == 0u) {
+        // a block header: minDelta and the widths of all its miniblocks (:67-94)
+        uint64_t u;
+        int hs = read_uvarint(B, c0, len, &pos, &u);
+        if (hs == PQ_OK) {
+            md = unzigzag(u);
+            if (sizeof(UT) == 4 && (md > 2147483647ll || md < -2147483648ll)) hs = PQ_INT32_OUT_OF_RANGE;
         }
+        if (hs == PQ_OK) {
+            const int64_t rem = len - pos;
+            if (rem <= 0) hs = PQ_EOF;
+            else if (rem < 4) hs = PQ_UNEXPECTED_EOF;
+            else {
+                const uint32_t o = (uint32_t)(pos - c0);
+                wd = (uint32_t)B[o] | ((uint32_t)B[o + 1] << 8) | ((uint32_t)B[o + 2] << 16) | ((uint32_t)B[o + 3] << 24);
+                pos += 4;
+                // any byte > 32 ?  (byte + 95 carries into bit 7, or bit 7 already set)
+                if ((((wd & 0x7f7f7f7fu) + 0x5f5f5f5fu) | wd) & 0x80808080u) hs = PQ_INVALID_MINIBLOCK_WIDTH;
+            }
+        }
+        if (hs != PQ_OK) {
+            st.status = hs;
+            if (p0 == 0) st.init_failed = 1;
+            st.n_ok = p0;
+            st.finished = 1;
+            return t;
+        }
+    } else {
+        wd = blk.wd;
+        md = blk.md_raw ? wave_raw_min_delta(blk.hdr_lo, blk.vl) : (int64_t)blk.md;
     }
-    if (hs != PQ_OK) {
-        st.status = hs;
-        if (p0 == 0) st.init_failed = 1;
-        st.n_ok = p0;
-        st.finished = 1;
-        return t;
-    }
-    const uint32_t prefix = wd * 0x01010100u;           // bytes: 0, w0, w0+w1, w0+w1+w2
-    const uint32_t total_w = (wd * 0x01010101u) >> 24;  // w0+w1+w2+w3 <= 128
+    const uint32_t tw = lg == 5u ? wd : (half ? wd >> 16 : wd & 0xffffu);  // widths of this tile's miniblocks
+    const uint32_t prefix = tw * 0x01010100u;           // bytes: 0, w0, w0+w1, w0+w1+w2
+    const uint32_t total_w = (tw * 0x01010101u) >> 24;  // their sum, <= 128
     const uint32_t tile_vals = min(128u, st.need - p0);
     const uint32_t gn = (tile_vals + 7u) >> 3;          // groups that will be read
     const int64_t avail = len - pos;
     uint32_t ok_groups = gn;
-    if ((int64_t)(4u * total_w) > avail || gn < 16u) {
-        // the block is the stream's last or is cut short: io.ReadFull per group (:111-114)
+    if ((int64_t)(G * total_w) > avail || gn < 16u) {
+        // the tile is the stream's last or is cut short: io.ReadFull per group (:111-114)
         int64_t off = 0;
-        for (uint32_t j = 0; j < 4u; ++j) {
-            const uint32_t w = (wd >> (8u * j)) & 0xffu;
-            if (gn <= 4u * j) break;
-            const uint32_t gj = min(4u, gn - 4u * j);
+        for (uint32_t j = 0; j < MT; ++j) {
+            const uint32_t w = (tw >> (8u * j)) & 0xffu;
+            if (gn <= G * j) break;
+            const uint32_t gj = min(G, gn - G * j);
             if (off + (int64_t)(gj * w) > avail) {
                 const int64_t rem = avail > off ? avail - off : 0;
                 const uint32_t gok = w ? (uint32_t)(rem / w) : gj;
-                ok_groups = 4u * j + gok;
+                ok_groups = G * j + gok;
                 st.status = (rem - (int64_t)gok * w) == 0 ? PQ_EOF : PQ_UNEXPECTED_EOF;
                 break;
             }
-            off += 4 * (int64_t)w;
+            off += (int64_t)G * (int64_t)w;
         }
     }
     t.valid = 1;
     t.p0 = p0;
     t.bitbase = (uint32_t)(pos - c0) * 8u;
-    t.widths = wd;
+    t.widths = tw;
     t.prefix = prefix;
     t.min_delta = (uint64_t)md;
     if (ok_groups > 0) {
-        const uint32_t gl = ok_groups - 1u; // last group read in this block
-        const uint32_t j = gl >> 2;
-        const uint32_t wj = (wd >> (8u * j)) & 0xffu;
-        st.end_pos = pos + 4 * (int64_t)((prefix >> (8u * j)) & 0xffu) + (int64_t)((gl & 3u) + 1u) * wj;
+        const uint32_t gl = ok_groups - 1u; // last group read in this tile
+        const uint32_t j = gl >> (lg - 3u);
+        const uint32_t wj = (tw >> (8u * j)) & 0xffu;
+        st.end_pos = pos + (int64_t)G * (int64_t)((prefix >> (8u * j)) & 0xffu) + (int64_t)((gl & (G - 1u)) + 1u) * wj;
         st.last_widths = wd;
-        st.last_group = gl;
+        st.last_group = gl + 16u * half;
     }
     if (st.status != PQ_OK) {
         st.n_ok = p0 + 8u * ok_groups;
@@ -195,8 +229,14 @@ __device__ __forceinline__ WaveTile wave_walk_slow(WaveState<UT> &st, const uint
         st.n_ok = st.need;
         st.finished = 1;
     }
-    st.pos = pos + 4 * (int64_t)total_w;
+    st.pos = pos + (int64_t)G * (int64_t)total_w;
     st.tiles_done += 1;
+    if (lg != 5u) {
+        blk.half = half ^ 1u;
+        blk.wd = wd;
+        blk.md_raw = 0;
+        blk.md = (uint64_t)md;
+    }
     return t;
 }
 
@@ -206,10 +246,31 @@ __device__ __forceinline__ WaveTile wave_walk_slow(WaveState<UT> &st, const uint
 // the block header, `lim` the window offset of the end of the stream, p0 the
 // position of the block's first value.  Returns false, changing nothing, whenever
 // any of that does not hold; the caller then takes wave_walk_slow.
+template <uint32_t LG>
 __device__ __forceinline__ bool wave_walk_fast(WaveTile &t, const uint32_t *lds, uint32_t &o, uint32_t lim,
-                                               uint32_t &p0, uint32_t need)
+                                               uint32_t &p0, uint32_t need, WaveBlock &blk)
 {
-    if (p0 + 128u >= need) return false; // the page's last block takes the checked path
+    constexpr uint32_t lg = LG;
+    if (p0 + 128u >= need) return false; // the page's last tile takes the checked path
+    if (lg != 5u && blk.half != 0u) {
+        // second half of a 256-value block: miniblocks 2 and 3 under the header already parsed
+        const uint32_t tw = blk.wd >> 16;
+        const uint32_t next = o + 8u * ((tw * 0x01010101u) >> 24);
+        if (next > lim) return false;
+        t.valid = 1;
+        t.p0 = p0;
+        t.bitbase = o * 8u;
+        t.widths = tw;
+        t.prefix = tw * 0x01010100u;
+        t.md_raw = blk.md_raw;
+        t.hdr_lo = blk.hdr_lo;
+        t.vl = blk.vl;
+        t.min_delta = blk.md;
+        blk.half = 0;
+        o = next;
+        p0 += 128u;
+        return true;
+    }
     const uint32_t k = o >> 2, s = (o & 3u) * 8u;
     const uint32_t d0 = uni(lds[k]), d1 = uni(lds[k + 1]), d2 = uni(lds[k + 2]);
     const uint32_t lo = (uint32_t)(((((uint64_t)d1) << 32) | d0) >> s);  // header bytes 0..3
@@ -219,18 +280,26 @@ __device__ __forceinline__ bool wave_walk_fast(WaveTile &t, const uint32_t *lds,
     const uint32_t vl = ((uint32_t)__builtin_ctz(stop) + 1u) >> 3;       // varint length 1..4
     const uint32_t wd = (uint32_t)(((((uint64_t)mid) << 32) | lo) >> (8u * vl));
     if ((((wd & 0x7f7f7f7fu) + 0x5f5f5f5fu) | wd) & 0x80808080u) return false; // a width > 32
-    const uint32_t total_w = (wd * 0x01010101u) >> 24;
+    const uint32_t tw = lg == 5u ? wd : wd & 0xffffu;                     // this tile's miniblocks
+    const uint32_t total_w = (tw * 0x01010101u) >> 24;
     const uint32_t data = o + vl + 4u;
-    const uint32_t next = data + 4u * total_w;
+    const uint32_t next = data + ((total_w << lg) >> 3);
     if (next > lim) return false;
     t.valid = 1;
     t.p0 = p0;
     t.bitbase = data * 8u;
-    t.widths = wd;
-    t.prefix = wd * 0x01010100u;
+    t.widths = tw;
+    t.prefix = tw * 0x01010100u;
     t.md_raw = 1;
     t.hdr_lo = lo;
     t.vl = vl;
+    if (lg != 5u) {  // the second half of the block will want its header
+        blk.half = 1u;
+        blk.wd = wd;
+        blk.md_raw = 1;
+        blk.hdr_lo = lo;
+        blk.vl = vl;
+    }
     o = next;
     p0 += 128u;
     return true;
@@ -244,19 +313,20 @@ __device__ __forceinline__ uint64_t wave_consumed(const WaveState<UT> &st, int64
     if (st.status != PQ_OK || st.n_ok == 0) return (uint64_t)pos;
     const uint32_t last_group_pos = ((st.n_ok - 1u) >> 3) << 3;
     if (last_group_pos + 8u < st.total) return (uint64_t)pos;
-    const uint32_t gl = st.last_group, j = gl >> 2;
+    const uint32_t G = 1u << (st.lg - 3u);  // groups per miniblock
+    const uint32_t gl = st.last_group, j = gl >> (st.lg - 3u);
     const int64_t wj = (st.last_widths >> (8u * j)) & 0xffu;
-    pos = min(len, pos + (int64_t)(3u - (gl & 3u)) * wj);
+    pos = min(len, pos + (int64_t)(G - 1u - (gl & (G - 1u))) * wj);
     if (j + 1u < 4u) {
         const int64_t bw = (st.last_widths >> (8u * (j + 1u))) & 0xffu;
-        for (uint32_t i = j + 1u; i < 4u; ++i) pos = min(len, pos + 4 * bw);
+        for (uint32_t i = j + 1u; i < 4u; ++i) pos = min(len, pos + (int64_t)G * bw);
     }
     return (uint64_t)pos;
 }
 
 // Per-lane constants of the decode.
 struct WaveLane {
-    uint32_t sh8; // 8 * miniblock index of this lane's 2 values
+    uint32_t sh8; // 8 * index (inside the tile) of the miniblock of this lane's 2 values
     uint32_t k2;  // index of the first of them inside the miniblock
 };
 
@@ -273,13 +343,13 @@ __device__ __forceinline__ int32_t wave_expand_min_delta(uint32_t hdr_lo, uint32
 }
 
 // CLIPPED = false: a whole block, stored unconditionally.
-template <typename UT, bool CLIPPED>
+template <typename UT, bool CLIPPED, uint32_t LG>
 __device__ __forceinline__ void wave_decode_tile(const uint32_t *lds, const WaveTile &t, UT &carry, UT *dst,
                                                  uint32_t clip, bool vec_ok, int lane, WaveLane ln)
 {
     const uint32_t w = __builtin_amdgcn_ubfe(t.widths, ln.sh8, 8u);
     const uint32_t pre = __builtin_amdgcn_ubfe(t.prefix, ln.sh8, 8u);
-    const uint32_t bit = t.bitbase + pre * 32u + ln.k2 * w;
+    const uint32_t bit = t.bitbase + (pre << LG) + ln.k2 * w;
     const uint32_t i = bit >> 5, s = bit & 31u;
     const uint32_t d0 = lds[i], d1 = lds[i + 1], d2 = lds[i + 2];
     const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, s);
@@ -343,9 +413,110 @@ struct WaveDeltaResult {
     uint32_t total;  // the value count the stream header declares (0 when the header failed)
 };
 
+// The tiles of one page behind its stream header (pos = the first block header, first = the first
+// value, the window [c0, c0 + kDwChunk) staged).  LG = log2 of the values per miniblock.
+template <typename UT, uint32_t LG>
+__device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const uint8_t *S, int64_t len, uint32_t n,
+                                                            UT *dst, int lane, WavePrefetch &pf, int64_t c0, int64_t pos,
+                                                            uint32_t total32, uint64_t first, bool vec_ok)
+{
+    WaveDeltaResult res{PQ_OK, 0, 0, 0, total32};
+    WaveState<UT> st;
+    st.pos = pos;
+    st.end_pos = pos;
+    st.tiles_done = 0;
+    st.total = total32;
+    st.need = min(n, total32);
+    st.n_ok = 0;
+    st.status = PQ_OK;
+    st.finished = 0;
+    st.init_failed = 0;
+    st.last_widths = 0;
+    st.last_group = 0;
+    st.lg = LG;
+    WaveBlock blk{0, 0, 0, 0, 0, 0};
+    const uint8_t *B = reinterpret_cast<const uint8_t *>(lds);
+
+    if (st.need == 0) {
+        // Init still reads the first block header eagerly (:198-204, :274-280); only
+        // its header errors count, and the reader stops right behind the width bytes
+        st.need = 1;
+        (void)wave_walk_slow<UT, LG>(st, blk, B, c0, len);
+        res.init_failed = uni(st.init_failed);
+        res.status = res.init_failed ? (int)uni((uint32_t)st.status) : PQ_OK;
+        int64_t p2 = pos;
+        uint64_t z;
+        if (!res.init_failed) {
+            (void)read_uvarint(B, c0, len, &p2, &z);
+            p2 += 4;
+        }
+        res.consumed = (uint64_t)uni((uint32_t)p2);
+        return res;
+    }
+
+    WaveLane ln;
+    ln.sh8 = ((2u * (uint32_t)lane) >> LG) * 8u;
+    ln.k2 = (2u * (uint32_t)lane) & ((1u << LG) - 1u);
+    UT carry = (UT)first;
+    uint32_t o = (uint32_t)(pos - c0); // window offset of the next block header
+    uint32_t p0 = 0;                   // position of that block's first value
+    while (true) {
+        // The window [c0, c0 + kDwChunk) is in LDS.  Windows advance by a fixed stride
+        // (a block never needs more than kDwBlockMax bytes, so whatever block straddles
+        // the end of this window starts inside the next one): the next window's loads
+        // do not depend on the walk and are issued before it, a whole window ahead.
+        const int64_t c1 = c0 + kDwStride;
+        const bool tail = c0 + kDwChunk >= len; // this window reaches the end of the stream
+        if (!tail) wave_fetch(pf, S, c1, len, lane);
+        const int64_t left = len - c0;
+        const uint32_t lim = left > (int64_t)kDwChunk ? (uint32_t)kDwChunk : (left < 0 ? 0u : (uint32_t)left);
+        while (!st.finished && (tail || o + (uint32_t)kDwBlockMax <= (uint32_t)kDwChunk)) {
+            WaveTile t = wave_tile_none();
+            if (wave_walk_fast<LG>(t, lds, o, lim, p0, st.need, blk)) {
+                wave_decode_tile<UT, false, LG>(lds, t, carry, dst, 0xffffffffu, vec_ok, lane, ln);
+                continue;
+            }
+            st.pos = c0 + (int64_t)o;
+            st.tiles_done = p0 >> 7;
+            t = wave_walk_slow<UT, LG>(st, blk, B, c0, len);
+            blk.half = uni(blk.half);
+            blk.wd = uni(blk.wd);
+            blk.md = ((uint64_t)uni((uint32_t)(blk.md >> 32)) << 32) | uni((uint32_t)blk.md);
+            // values the checked path read back from LDS are uniform too
+            o = uni((uint32_t)(st.pos - c0));
+            p0 = uni(st.tiles_done) * 128u;
+            st.finished = uni(st.finished);
+            st.status = (int32_t)uni((uint32_t)st.status);
+            st.n_ok = uni(st.n_ok);
+            t.valid = uni(t.valid);
+            t.bitbase = uni(t.bitbase);
+            t.widths = uni(t.widths);
+            t.prefix = uni(t.prefix);
+            t.p0 = uni(t.p0);
+            t.min_delta = ((uint64_t)uni((uint32_t)(t.min_delta >> 32)) << 32) | uni((uint32_t)t.min_delta);
+            const uint32_t clip = st.finished ? st.n_ok : 0xffffffffu;
+            if (t.valid) wave_decode_tile<UT, true, LG>(lds, t, carry, dst, clip, vec_ok, lane, ln);
+        }
+        if (st.finished) break;
+        wave_sync();
+        wave_commit(lds, pf, lane);
+        wave_sync();
+        c0 = c1;
+        o -= (uint32_t)kDwStride;
+    }
+
+    res.status = st.status;
+    res.n_decoded = st.n_ok;
+    res.init_failed = st.init_failed;
+    if (st.status == PQ_OK && n > st.total) res.status = PQ_EOF; // pulled past the declared count
+    res.consumed = wave_consumed<UT>(st, len);
+    return res;
+}
+
 // Decode one page with one wave.  `lds` is this wave's private window.  A stream that
-// declares more than `cap` values is not decoded at all (status kOverCap).
-template <typename UT>
+// declares more than `cap` values is not decoded at all (status kOverCap).  WIDE = false: only
+// the 128 / 4 layout is taken (for callers whose streams never use the other one).
+template <typename UT, bool WIDE = true>
 __device__ __forceinline__ WaveDeltaResult delta_wave(uint32_t *lds, const uint8_t *S, int64_t len, uint32_t n,
                                                       UT *dst, int lane, uint32_t cap = 0xffffffffu)
 {
@@ -406,96 +577,17 @@ __device__ __forceinline__ WaveDeltaResult delta_wave(uint32_t *lds, const uint8
         res.consumed = (uint64_t)pos;
         return res;
     }
-    if (uni((uint32_t)bs) != 128u || uni((uint32_t)nm) != 4u) {
+    // tiles of 128 values: blocks of 128 with 4 miniblocks of 32, or blocks of 256 with 4 of 64
+    const uint32_t bs32 = uni((uint32_t)bs);
+    if ((bs32 != 128u && !(WIDE && bs32 == 256u)) || uni((uint32_t)nm) != 4u) {
         res.status = kNeedGeneric;
         return res;
     }
     first = ((uint64_t)uni((uint32_t)(first >> 32)) << 32) | uni((uint32_t)first);
-
-    WaveState<UT> st;
-    st.pos = pos;
-    st.end_pos = pos;
-    st.tiles_done = 0;
-    st.total = total32;
-    st.need = min(n, total32);
-    st.n_ok = 0;
-    st.status = PQ_OK;
-    st.finished = 0;
-    st.init_failed = 0;
-    st.last_widths = 0;
-    st.last_group = 0;
-
-    if (st.need == 0) {
-        // Init still reads the first block header eagerly (:198-204, :274-280); only
-        // its header errors count, and the reader stops right behind the width bytes
-        st.need = 1;
-        (void)wave_walk_slow<UT>(st, B, c0, len);
-        res.init_failed = uni(st.init_failed);
-        res.status = res.init_failed ? (int)uni((uint32_t)st.status) : PQ_OK;
-        int64_t p2 = pos;
-        uint64_t z;
-        if (!res.init_failed) {
-            (void)read_uvarint(B, c0, len, &p2, &z);
-            p2 += 4;
-        }
-        res.consumed = (uint64_t)uni((uint32_t)p2);
-        return res;
+    if constexpr (WIDE) {
+        if (bs32 == 256u) return delta_wave_tiles<UT, 6>(lds, S, len, n, dst, lane, pf, c0, pos, total32, first, vec_ok);
     }
-
-    WaveLane ln;
-    ln.sh8 = (uint32_t)(lane >> 4) * 8u;
-    ln.k2 = 2u * (uint32_t)(lane & 15);
-    UT carry = (UT)first;
-    uint32_t o = (uint32_t)(pos - c0); // window offset of the next block header
-    uint32_t p0 = 0;                   // position of that block's first value
-    while (true) {
-        // The window [c0, c0 + kDwChunk) is in LDS.  Windows advance by a fixed stride
-        // (a block never needs more than kDwBlockMax bytes, so whatever block straddles
-        // the end of this window starts inside the next one): the next window's loads
-        // do not depend on the walk and are issued before it, a whole window ahead.
-        const int64_t c1 = c0 + kDwStride;
-        const bool tail = c0 + kDwChunk >= len; // this window reaches the end of the stream
-        if (!tail) wave_fetch(pf, S, c1, len, lane);
-        const int64_t left = len - c0;
-        const uint32_t lim = left > (int64_t)kDwChunk ? (uint32_t)kDwChunk : (left < 0 ? 0u : (uint32_t)left);
-        while (!st.finished && (tail || o + (uint32_t)kDwBlockMax <= (uint32_t)kDwChunk)) {
-            WaveTile t = wave_tile_none();
-            if (wave_walk_fast(t, lds, o, lim, p0, st.need)) {
-                wave_decode_tile<UT, false>(lds, t, carry, dst, 0xffffffffu, vec_ok, lane, ln);
-                continue;
-            }
-            st.pos = c0 + (int64_t)o;
-            st.tiles_done = p0 >> 7;
-            t = wave_walk_slow<UT>(st, B, c0, len);
-            // values the checked path read back from LDS are uniform too
-            o = uni((uint32_t)(st.pos - c0));
-            p0 = uni(st.tiles_done) * 128u;
-            st.finished = uni(st.finished);
-            st.status = (int32_t)uni((uint32_t)st.status);
-            st.n_ok = uni(st.n_ok);
-            t.valid = uni(t.valid);
-            t.bitbase = uni(t.bitbase);
-            t.widths = uni(t.widths);
-            t.prefix = uni(t.prefix);
-            t.p0 = uni(t.p0);
-            t.min_delta = ((uint64_t)uni((uint32_t)(t.min_delta >> 32)) << 32) | uni((uint32_t)t.min_delta);
-            const uint32_t clip = st.finished ? st.n_ok : 0xffffffffu;
-            if (t.valid) wave_decode_tile<UT, true>(lds, t, carry, dst, clip, vec_ok, lane, ln);
-        }
-        if (st.finished) break;
-        wave_sync();
-        wave_commit(lds, pf, lane);
-        wave_sync();
-        c0 = c1;
-        o -= (uint32_t)kDwStride;
-    }
-
-    res.status = st.status;
-    res.n_decoded = st.n_ok;
-    res.init_failed = st.init_failed;
-    if (st.status == PQ_OK && n > st.total) res.status = PQ_EOF; // pulled past the declared count
-    res.consumed = wave_consumed<UT>(st, len);
-    return res;
+    return delta_wave_tiles<UT, 5>(lds, S, len, n, dst, lane, pf, c0, pos, total32, first, vec_ok);
 }
 
 } // namespace pq

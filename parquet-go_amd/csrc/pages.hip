@@ -75,9 +75,10 @@ __device__ __forceinline__ HybridResult run_section(HybridShared &sh, const Sect
 }
 
 // Levels from ConstDecoder(0) (encoding/const.go:7-19): n zeros, nothing read.
-__device__ __forceinline__ HybridResult const_levels(uint32_t *dst, uint32_t n, uint32_t max_level)
+__device__ __forceinline__ HybridResult const_levels(uint32_t *dst, uint32_t n, uint32_t max_level, bool write = true)
 {
-    for (uint32_t i = threadIdx.x; i < n; i += kWG) dst[i] = 0;
+    if (write)
+        for (uint32_t i = threadIdx.x; i < n; i += kWG) dst[i] = 0;
     HybridResult r{PQ_OK, n, max_level == 0 ? n : 0u, 0};
     return r;
 }
@@ -449,13 +450,14 @@ __device__ __forceinline__ void data_page_wg(PageShared &sh, uint32_t *ldict, co
     int32_t lvl_status = PQ_OK, lvl_stage = PQ_STAGE_NONE;
     uint32_t not_null = 0;
     if (size != 0) {
-        HybridResult rr = konst ? const_levels(rep_dst, size, d.max_rep)
+        const bool zeros_out = (d.flags & PQ_FLAG_NO_LEVEL_OUTPUT) == 0u;
+        HybridResult rr = konst ? const_levels(rep_dst, size, d.max_rep, zeros_out)
                                 : run_section<HY_LEVELS, uint32_t>(sh.hy, rep, wr, size, rep_dst, nullptr, 0, d.max_rep);
         if (rr.status != PQ_OK) {
             lvl_status = rr.status;
             lvl_stage = PQ_STAGE_REP;
         } else {
-            HybridResult dr = konst ? const_levels(def_dst, size, d.max_def)
+            HybridResult dr = konst ? const_levels(def_dst, size, d.max_def, zeros_out)
                                     : run_section<HY_LEVELS, uint32_t>(sh.hy, def, wd, size, def_dst, nullptr, 0, d.max_def);
             if (dr.status != PQ_OK) {
                 lvl_status = dr.status;
@@ -595,9 +597,11 @@ __device__ __forceinline__ HybridResult run_section_wave(HybridWaveLds &L, const
     return hybrid_wave<MODE, OutT>(L, sec.S, sec.len, w, n, dst, dict, dict_len, max_level, lane);
 }
 
-__device__ __forceinline__ HybridResult const_levels_wave(uint32_t *dst, uint32_t n, uint32_t max_level, int lane)
+__device__ __forceinline__ HybridResult const_levels_wave(uint32_t *dst, uint32_t n, uint32_t max_level, int lane,
+                                                          bool write = true)
 {
-    for (uint32_t i = (uint32_t)lane; i < n; i += kWave) dst[i] = 0;
+    if (write)
+        for (uint32_t i = (uint32_t)lane; i < n; i += kWave) dst[i] = 0;
     HybridResult r{PQ_OK, n, max_level == 0 ? n : 0u, 0};
     return r;
 }
@@ -822,14 +826,15 @@ __global__ __launch_bounds__(kHwWG) void data_wave_kernel(const pq_page_desc *__
     int32_t lvl_status = PQ_OK, lvl_stage = PQ_STAGE_NONE;
     uint32_t not_null = 0;
     if (size != 0) {
-        HybridResult rr = konst ? const_levels_wave(rep_dst, size, d.max_rep, lane)
+        const bool zeros_out = (d.flags & PQ_FLAG_NO_LEVEL_OUTPUT) == 0u;
+        HybridResult rr = konst ? const_levels_wave(rep_dst, size, d.max_rep, lane, zeros_out)
                                 : run_section_wave<HY_LEVELS, uint32_t>(L, rep, wr, size, rep_dst, nullptr, 0,
                                                                          d.max_rep, lane);
         if (rr.status != PQ_OK) {
             lvl_status = rr.status;
             lvl_stage = PQ_STAGE_REP;
         } else {
-            HybridResult dr = konst ? const_levels_wave(def_dst, size, d.max_def, lane)
+            HybridResult dr = konst ? const_levels_wave(def_dst, size, d.max_def, lane, zeros_out)
                                     : run_section_wave<HY_LEVELS, uint32_t>(L, def, wdw, size, def_dst, nullptr, 0,
                                                                              d.max_def, lane);
             if (dr.status != PQ_OK) {

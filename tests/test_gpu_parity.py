@@ -410,8 +410,8 @@ def test_delta_random_vs_oracle(ctx, bits):
             base = int(rng.integers(-1000, 1000))
             with np.errstate(over="ignore"):
                 vals = (np.cumsum(steps + base) + int(rng.integers(-2**40, 2**40))).astype(dt)
-            for block, mb in ((128, 4), (256, 8), (512, 4), (1024, 4), (128, 1)):
-                if n > 3000 and (block, mb) != (128, 4):
+            for block, mb in ((128, 4), (256, 4), (256, 8), (512, 4), (1024, 4), (128, 1)):
+                if n > 3000 and (block, mb) not in ((128, 4), (256, 4)):
                     continue
                 stream = synth.delta_encode(vals, bits, block, mb)
                 for pull in sorted({n, max(n - 1, 0), n + 2, n // 2}):
@@ -428,13 +428,14 @@ def test_delta_truncated_at_every_byte(ctx, bits):
     rng = _rng(30 + bits)
     kind = K.KIND_DELTA32 if bits == 32 else K.KIND_DELTA64
     dt = np.int32 if bits == 32 else np.int64
-    vals = np.cumsum(rng.integers(-50, 1 << 11, size=300)).astype(dt)
-    stream = synth.delta_encode(vals, bits, 128, 4)
     cases = []
-    for cut in range(stream.size + 1):
-        c = Case(kind, stream[:cut].copy(), 300)
-        c.result_src_len = cut
-        cases.append(c)
+    for block, count in ((128, 300), (256, 300), (256, 600), (256, 385)):   # blocks of 128 and of 256 values
+        vals = np.cumsum(rng.integers(-50, 1 << 11, size=count)).astype(dt)
+        stream = synth.delta_encode(vals, bits, block, 4)
+        for cut in range(stream.size + 1):
+            c = Case(kind, stream[:cut].copy(), count)
+            c.result_src_len = cut
+            cases.append(c)
     _run_delta_both_ways(ctx, cases, bits, seed=7)
 
 
@@ -444,7 +445,7 @@ def test_delta_fuzz_headers_and_bodies(ctx, bits):
     path handles (miniblocks that are not whole groups or do not tile 128)."""
     rng = _rng(40 + bits)
     kind = K.KIND_DELTA32 if bits == 32 else K.KIND_DELTA64
-    layouts = [(128, 4), (128, 2), (128, 8), (128, 16), (256, 1), (256, 2), (384, 3), (384, 16), (128, 128),
+    layouts = [(128, 4), (256, 4), (256, 4), (128, 2), (128, 8), (128, 16), (256, 1), (256, 2), (384, 3), (384, 16), (128, 128),
                (128, 64), (128, 32), (640, 5), (1024, 2), (2048, 1), (128, 3), (0, 4), (100, 4), (256, 256)]
     cases = []
     for i in range(400):
@@ -540,6 +541,37 @@ def test_data_pages_vs_oracle(ctx):
     run_cases(ctx, cases, seed=9)
     for c in cases:
         _check_page(c)
+
+
+def test_flat_pages_without_level_output(ctx):
+    """PQ_FLAG_NO_LEVEL_OUTPUT: pages of a column with max_rep == 0 (both level decoders are ConstDecoder(0),
+    layout/chunk.go:111-124) decode to the same result without writing their all-zero levels."""
+    rng = _rng(55)
+    d32 = rng.integers(-2**31, 2**31, size=300, dtype=np.int64).astype(np.int32)
+    cases = []
+    for version in (1, 2):
+        kind = K.KIND_PAGE_V1 if version == 1 else K.KIND_PAGE_V2
+        for n in (0, 7, 5000):
+            for max_def in (0, 1):
+                for vk, dic in ((K.KIND_DICT, d32), (K.KIND_DELTA64, None), (K.KIND_PLAIN, None)):
+                    src, rl, dl = _make_page(rng, version, n, 0, max_def, vk, dic, plain_dtype=np.int64)
+                    cases.append(Case(kind, src, n, max_rep=0, max_def=max_def, value_kind=vk, dictionary=dic,
+                                      rep_len=rl, def_len=dl, flags=K.FLAG_NO_LEVEL_OUTPUT,
+                                      **({"plain_dtype": np.int64} if vk == K.KIND_PLAIN else {})))
+    run_cases(ctx, cases, seed=10)
+    for c in cases:
+        want = O.page_read(c.src, 1 if c.kind == K.KIND_PAGE_V1 else 2, c.n, 0, c.max_def,
+                           {K.KIND_DICT: O.VALUES_DICT, K.KIND_DELTA64: O.VALUES_DELTA64, K.KIND_PLAIN: O.VALUES_PLAIN}[c.value_kind],
+                           dictionary=c.dictionary, rep_len=c.rep_len, def_len=c.def_len, value_dtype=c.plain_dtype)
+        r = c.result
+        assert (r["status"], r["stage"], r["detail"], r["n_levels"]) == (want["status"], want["stage"], want["detail"], want["n"])
+        if want["status"] == O.OK and c.n:
+            assert r["not_null"] == want["not_null"]
+            nn = want["not_null"]
+            assert np.array_equal(c.values[:nn].view(np.uint8), want["values"][:nn].view(np.uint8))
+        assert not guard_ok(np.zeros(1, np.int32))
+        assert guard_ok(c.def_levels) and guard_ok(c.rep_levels)      # untouched
+        assert guard_ok(c.guard) and guard_ok(c.def_guard) and guard_ok(c.rep_guard)
 
 
 def test_plain_and_boolean_vs_oracle(ctx, golden_dir):

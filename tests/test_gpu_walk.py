@@ -161,6 +161,10 @@ def test_pyarrow_file_end_to_end(ctx, tmp_path, version, page_size):
     plan.close()
     assert (results["status"] == K.OK).all(), results[results["status"] != 0][:3]
     values, levels = t_val.cpu().numpy(), t_lvl.cpu().numpy()
+    nested = sum(int(descs[k]["n_values"]) for i, r in enumerate(recs) if r["max_rep"]
+                 for k in range(spans[i][0], spans[i][0] + spans[i][1]))
+    assert int(layout["levels_off"][0]) == 8 * nested          # only the nested column's levels take room
+    assert (levels[8 * nested:] == 0xA5).all()
 
     for i, r in enumerate(recs):
         first, cnt = spans[i]
@@ -178,6 +182,9 @@ def test_pyarrow_file_end_to_end(ctx, tmp_path, version, page_size):
                     int(d["value_kind"]), int(d["elem_size"]))
                 vals.append(values[int(d["dst_off"]): int(d["dst_off"]) + es * nn])
             nl = int(d["n_values"])
+            if r["max_rep"] == 0:           # flat column: the constant-zero levels are not written
+                assert d["flags"] & K.FLAG_NO_LEVEL_OUTPUT
+                continue
             defs.append(levels[int(d["def_off"]): int(d["def_off"]) + 4 * nl].view(np.int32))
             reps.append(levels[int(d["rep_off"]): int(d["rep_off"]) + 4 * nl].view(np.int32))
         if isinstance(want_vals, list):
