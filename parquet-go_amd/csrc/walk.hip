@@ -36,15 +36,24 @@ struct WalkReader {
     const uint8_t *S;   // chunk byte 0
     int64_t len;
     int64_t c0;         // stream offset of the window (far below zero: nothing staged)
-    int64_t pos;
+    int64_t next;       // stream offset of the byte behind the register buffer
     uint64_t buf;       // the next `have` bytes of the stream, lowest byte first
-    uint32_t have;
+    uint32_t have;      // 0..8; the read position is next - have
     int lane;
 };
 
-__device__ __forceinline__ void wk_stage(WalkReader &r)
+__device__ __forceinline__ int64_t wk_pos(const WalkReader &r) { return r.next - (int64_t)r.have; }
+
+// Move the read position (the register buffer is dropped).
+__device__ __forceinline__ void wk_seek(WalkReader &r, int64_t pos)
 {
-    r.c0 = chunk_base(r.S, r.pos);
+    r.next = pos;
+    r.have = 0;
+}
+
+__device__ __forceinline__ void wk_stage(WalkReader &r, int64_t pos)
+{
+    r.c0 = chunk_base(r.S, pos);
     const int64_t o = r.c0 + 16 * (int64_t)r.lane;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (o + 16 > 0 && o < r.len) v = *reinterpret_cast<const uint4 *>(r.S + o);
@@ -53,42 +62,51 @@ __device__ __forceinline__ void wk_stage(WalkReader &r)
     wave_sync();
 }
 
-// Eight stream bytes from pos on into the register buffer: a header is parsed from registers,
-// one trip to LDS per eight bytes instead of one per byte.
-__device__ __forceinline__ void wk_refill(WalkReader &r)
+// Up to eight stream bytes from the read position on into the register buffer: a header is
+// parsed from registers, one trip to LDS per eight bytes instead of one per byte, and all the
+// 64-bit position arithmetic happens here, not per byte.  false: the source is exhausted.
+__device__ __forceinline__ bool wk_refill(WalkReader &r)
 {
-    if (r.pos < r.c0 || r.pos + 8 > r.c0 + kWkWin) wk_stage(r);  // a window starts at most 15 bytes below pos
-    const uint32_t o = (uint32_t)(r.pos - r.c0);
+    const int64_t pos = r.next;  // have == 0
+    if (pos >= r.len) return false;
+    if (pos < r.c0 || pos + 8 > r.c0 + kWkWin) wk_stage(r, pos);  // a window starts at most 15 bytes below pos
+    const uint32_t o = (uint32_t)(pos - r.c0);
     const uint32_t *w = r.lds + (o >> 2);
     const uint32_t sh = (o & 3u) * 8u;
     // every lane holds the same bytes: saying so keeps the whole parse on the scalar unit
     const uint32_t lo = uni(__builtin_amdgcn_alignbit(w[1], w[0], sh));
     const uint32_t hi = uni(__builtin_amdgcn_alignbit(w[2], w[1], sh));
     r.buf = ((uint64_t)hi << 32) | lo;
-    r.have = 8;
+    const int64_t left = r.len - pos;
+    r.have = left < 8 ? (uint32_t)left : 8u;
+    r.next = pos + (int64_t)r.have;
+    return true;
 }
 
 // ReadByte: false when the source is exhausted
 __device__ __forceinline__ bool wk_byte(WalkReader &r, uint32_t *b)
 {
-    if (r.pos >= r.len) return false;
-    if (r.have == 0) wk_refill(r);
+    if (r.have == 0u && !wk_refill(r)) return false;
     *b = (uint32_t)r.buf & 255u;
     r.buf >>= 8;
-    r.have -= 1;
-    r.pos += 1;
+    r.have -= 1u;
     return true;
 }
 
 // io.ReadFull of n bytes nobody looks at
 __device__ __forceinline__ bool wk_advance(WalkReader &r, uint64_t n)
 {
-    r.have = 0;
-    if ((uint64_t)(r.len - r.pos) < n) {
-        r.pos = r.len;
+    if (n <= (uint64_t)r.have) {  // still inside the register buffer
+        r.buf = n < 8u ? r.buf >> (8u * (uint32_t)n) : 0ull;
+        r.have -= (uint32_t)n;
+        return true;
+    }
+    const int64_t pos = wk_pos(r);
+    if ((uint64_t)(r.len - pos) < n) {
+        wk_seek(r, r.len);
         return false;
     }
-    r.pos += (int64_t)n;
+    wk_seek(r, pos + (int64_t)n);
     return true;
 }
 
@@ -336,11 +354,11 @@ __device__ __forceinline__ bool wk_decoder_exists(uint32_t type, int32_t type_le
 // readBlockData (layout/block.go:17-47)
 __device__ __forceinline__ int32_t wk_block(WalkReader &r, uint32_t codec, int32_t compressed, int32_t uncompressed)
 {
-    const uint64_t left = (uint64_t)(r.len - r.pos);
+    const int64_t pos = wk_pos(r);
+    const uint64_t left = (uint64_t)(r.len - pos);
     const uint64_t want = compressed > 0 ? (uint64_t)compressed : 0ull;  // io.LimitReader(in, negative) reads nothing
     const uint64_t got = want < left ? want : left;
-    r.pos += (int64_t)got;
-    r.have = 0;
+    wk_seek(r, pos + (int64_t)got);
     if ((int64_t)got != (int64_t)compressed) return PQ_WALK_BLOCK_SIZE;
     if (codec == 0 && compressed != uncompressed) return PQ_WALK_UNCOMPRESSED_SIZE;
     return PQ_OK;
@@ -364,7 +382,7 @@ __global__ __launch_bounds__(kWkWaves *kWave) void walk_chunks_kernel(const pq_c
     r.S = src + c.src_off;
     r.len = (int64_t)c.src_len;
     r.c0 = INT64_MIN / 2;
-    r.pos = 0;
+    r.next = 0;
     r.buf = 0;
     r.have = 0;
     r.lane = lane;
@@ -377,11 +395,11 @@ __global__ __launch_bounds__(kWkWaves *kWave) void walk_chunks_kernel(const pq_c
     pq_page_info *out = infos + c.info_first;
     while (true) {
         if (c.total_compressed_size - count < 1) break;  // chunk.go:136
-        const int64_t h0 = r.pos;
+        const int64_t h0 = wk_pos(r);
         PageHeader h;
         if (!wk_page_header(r, h)) {
             st = PQ_WALK_HEADER_FAILED;
-            count += r.pos - h0;
+            count += wk_pos(r) - h0;
             break;
         }
         if (n >= c.info_cap) {
@@ -398,7 +416,7 @@ __global__ __launch_bounds__(kWkWaves *kWave) void walk_chunks_kernel(const pq_c
         pi.def_encoding = pi.rep_encoding = 0;
         pi.is_compressed = 1;
         pi.header_off = (uint64_t)h0;
-        pi.data_off = (uint64_t)r.pos;
+        pi.data_off = (uint64_t)wk_pos(r);
         bool seek = false;
         if (h.type == 2) {  // DICTIONARY_PAGE (chunk.go:148-180, page-dict.go:28-57)
             if (have_dict)
@@ -415,7 +433,7 @@ __global__ __launch_bounds__(kWkWaves *kWave) void walk_chunks_kernel(const pq_c
             pi.encoding = h.dict.f[2];
             if (st == PQ_OK) st = wk_block(r, c.codec, h.compressed, h.uncompressed);
             have_dict = true;
-            seek = st == PQ_OK && c.has_dictionary_page_offset && c.dictionary_page_offset != start + r.pos;
+            seek = st == PQ_OK && c.has_dictionary_page_offset && c.dictionary_page_offset != start + wk_pos(r);
         } else if (h.type == 0) {  // DATA_PAGE: init (page-v1.go:21-38), read (:40-67)
             if (!h.data.present)
                 st = PQ_WALK_MISSING_HEADER;
@@ -453,7 +471,7 @@ __global__ __launch_bounds__(kWkWaves *kWave) void walk_chunks_kernel(const pq_c
         } else {
             st = PQ_WALK_PAGE_TYPE;
         }
-        count += r.pos - h0;
+        count += wk_pos(r) - h0;
         if (st != PQ_OK) break;
         if (lane == 0) out[n] = pi;
         ++n;
@@ -463,9 +481,8 @@ __global__ __launch_bounds__(kWkWaves *kWave) void walk_chunks_kernel(const pq_c
                 st = PQ_WALK_SEEK;
                 break;
             }
-            count += target - r.pos;
-            r.pos = target > r.len ? r.len : target;
-            r.have = 0;
+            count += target - wk_pos(r);
+            wk_seek(r, target > r.len ? r.len : target);
         }
     }
     if (lane == 0) {

@@ -326,7 +326,7 @@ def bench_walk(ctx, stream, n_chunks, pages_per_chunk, body, with_statistics=Tru
     infos = t_infos.cpu().numpy().view(capi.PAGE_INFO_DTYPE)
     assert (infos["num_values"] == 20000).all() and (infos["compressed_size"] == body).all()
     t = float(np.median(times[1:]))
-    print(json.dumps({"config": "W page-header walk", "chunks": n_chunks, "pages_per_chunk": pages_per_chunk,
+    print(json.dumps({"config": "W page-header walk", "chunks": n_chunks, "pages_per_chunk": pages_per_chunk, "body": body,
                       "ms_per_call": round(t * 1e3, 3), "pages_per_s": round(n_chunks * pages_per_chunk / t),
                       "us_per_page_of_a_chunk": round(t * 1e6 / pages_per_chunk, 3),
                       "header_bytes": int(np.mean([h.size for h in heads]))}), flush=True)
@@ -397,6 +397,9 @@ def main():
         bench_walk(ctx, stream, 64, 800, 20000)
         bench_walk(ctx, stream, 1024, 100, 20000)
         bench_walk(ctx, stream, 64, 800, 20000, with_statistics=False)
+    if want("walk_probe"):   # bodies so short that several headers share a window: the parse without the memory misses
+        bench_walk(ctx, stream, 64, 800, 64)
+        bench_walk(ctx, stream, 64, 800, 64, with_statistics=False)
     if want("levels"):
         bench_levels(ctx, stream, 100_000_000)
     print("elapsed %.1fs" % (time.time() - t0), file=sys.stderr)
