@@ -263,8 +263,8 @@ int pq_delta_length_ba_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, u
                               uint64_t *consumed, int *init_failed);
 /* ByteArrayDeltaDecoder.Init(reader) + DecodeValues(dest[:n]) (types/byte-array.go:279-348).
  * offsets: n + 1 entries; data: data_cap bytes (< 2^32).  Returns PQ_ERR_OUT_OF_RANGE when the
- * values need more than data_cap bytes; *data_need (may be NULL) then holds nothing useful, the
- * caller retries with a larger area. */
+ * values need more than data_cap bytes (prefix expansion has no bound from the stream's size):
+ * the caller retries with a larger area. */
 int pq_delta_ba_decode(pq_ctx *ctx, const uint8_t *src, size_t src_len, uint32_t n,
                        uint32_t *offsets, uint8_t *data, size_t data_cap, uint32_t *n_decoded,
                        uint64_t *consumed, int *init_failed);

@@ -391,6 +391,25 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
         delete plan;
         return PQ_ERR_HIP;
     }
+    // Longest first: a launch ends with its slowest wave, so descriptors that take long (large
+    // pages, byte arrays) are dispatched before the short ones that can fill the tail.  Work is
+    // bucketed by half powers of two, and the order inside a bucket stays the caller's, so a
+    // plan of like pages keeps its order (and its locality).
+    auto work_bucket = [&](uint32_t i) -> uint32_t {
+        const pq_page_desc &d = descs[i];
+        uint64_t w = d.src_len + (uint64_t)d.n_values * std::max<uint32_t>(value_size(d), 4u) + 1;
+        if (byte_array_kind(d)) w *= 4;
+        const uint32_t b = 63u - (uint32_t)__builtin_clzll(w);
+        return 2u * b + (b ? (uint32_t)((w >> (b - 1u)) & 1u) : 0u);
+    };
+    std::vector<uint8_t> bucket(n_pages);
+    for (size_t i = 0; i < n_pages; ++i) bucket[i] = (uint8_t)work_bucket((uint32_t)i);
+    for (int g = 0; g < 4; ++g) {
+        bool mixed = false;
+        for (uint32_t i : ids[g]) mixed = mixed || bucket[i] != bucket[ids[g][0]];
+        if (mixed)
+            std::stable_sort(ids[g].begin(), ids[g].end(), [&](uint32_t a, uint32_t b) { return bucket[a] > bucket[b]; });
+    }
     std::vector<uint32_t> all;
     all.reserve(n_pages);
     for (int g = 0; g < 4; ++g) {
