@@ -348,6 +348,22 @@ int pq_chunk_page_descs(const pq_chunk_desc *chunk, const pq_page_info *infos, u
                         pq_chunk_layout *layout, pq_page_desc *descs, uint32_t *n_descs,
                         uint64_t *dict_src, uint64_t *dict_dst, uint64_t *dict_bytes);
 
+/* The same for every walked chunk of a row group in one call.  infos: the table pq_walk_chunks
+ * filled (chunk i's records at chunks[i].info_first, results[i].n_pages of them); chunks whose
+ * walk failed are skipped (no descriptors).  descs: room for descs_cap descriptors
+ * (PQ_ERR_OUT_OF_RANGE when they do not fit); first_desc: n_chunks + 1 entries, chunk i's
+ * descriptors are descs[first_desc[i] .. first_desc[i + 1]); copies: room for n_chunks
+ * dictionary copies (source offset in src, destination offset in the dictionary buffer, bytes). */
+typedef struct pq_dict_copy {
+    uint64_t src;
+    uint64_t dst;
+    uint64_t bytes;
+} pq_dict_copy;
+
+int pq_chunks_page_descs(const pq_chunk_desc *chunks, const pq_chunk_result *results, size_t n_chunks,
+                         const pq_page_info *infos, pq_chunk_layout *layout, pq_page_desc *descs,
+                         size_t descs_cap, uint32_t *first_desc, pq_dict_copy *copies, uint32_t *n_copies);
+
 /* ---- Level post-processing: what the reference does with decoded levels, value by value ----
  *
  * pq_levels_pack*: the bytes of an encoding.PackedArray (encoding/packed-array.go:47-55,118-125,

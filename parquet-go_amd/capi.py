@@ -37,7 +37,7 @@ EXPORTS = [
     "pq_delta_decode64", "pq_plain_decode", "pq_bool_plain_decode",
     "pq_levels_pack_dev", "pq_levels_pack", "pq_column_entries_dev", "pq_column_entries",
     "pq_delta_length_ba_decode", "pq_delta_ba_decode",
-    "pq_walk_chunks_dev", "pq_walk_chunks", "pq_chunk_page_descs",
+    "pq_walk_chunks_dev", "pq_walk_chunks", "pq_chunk_page_descs", "pq_chunks_page_descs",
 ]
 
 
@@ -160,6 +160,8 @@ def load():
                                            C.c_size_t, C.c_void_p]
         lib.pq_chunk_page_descs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pq_chunks_page_descs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -453,3 +455,25 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+DICT_COPY_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("bytes", "<u8")])
+
+
+def chunks_page_descs(chunks, results, infos, layout):
+    """pq_chunks_page_descs: descriptors for every walked chunk in one call.
+    -> (descs, first_desc[n_chunks + 1], dictionary copies)"""
+    lib = load()
+    ch = np.ascontiguousarray(chunks, dtype=CHUNK_DTYPE)
+    res = np.ascontiguousarray(results, dtype=CHUNK_RESULT_DTYPE)
+    inf = np.ascontiguousarray(infos, dtype=PAGE_INFO_DTYPE)
+    cap = int(res["n_pages"].sum())
+    descs = np.zeros(max(cap, 1), dtype=DESC_DTYPE)
+    first = np.zeros(ch.size + 1, dtype=np.uint32)
+    copies = np.zeros(max(ch.size, 1), dtype=DICT_COPY_DTYPE)
+    nc = C.c_uint32(0)
+    st = lib.pq_chunks_page_descs(_ptr(ch), _ptr(res), ch.size, _ptr(inf), _ptr(layout), _ptr(descs), cap,
+                                  _ptr(first), _ptr(copies), C.byref(nc))
+    if st != OK:
+        raise PqError(st, "(pq_chunks_page_descs) " + status_string(st))
+    return descs[:int(first[-1])], first, copies[:nc.value]

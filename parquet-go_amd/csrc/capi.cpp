@@ -897,6 +897,32 @@ int pq_chunk_page_descs(const pq_chunk_desc *chunk, const pq_page_info *infos, u
     return PQ_OK;
 }
 
+int pq_chunks_page_descs(const pq_chunk_desc *chunks, const pq_chunk_result *results, size_t n_chunks,
+                         const pq_page_info *infos, pq_chunk_layout *layout, pq_page_desc *descs, size_t descs_cap,
+                         uint32_t *first_desc, pq_dict_copy *copies, uint32_t *n_copies)
+{
+    if (!layout || !first_desc || !n_copies || (n_chunks && (!chunks || !results || !infos || !copies)))
+        return PQ_ERR_BAD_ARGUMENT;
+    size_t out = 0;
+    uint32_t nc = 0;
+    for (size_t i = 0; i < n_chunks; ++i) {
+        first_desc[i] = (uint32_t)out;
+        if (results[i].status != PQ_OK) continue;
+        const uint32_t np = results[i].n_pages;
+        if (out + np > descs_cap || (np && !descs)) return PQ_ERR_OUT_OF_RANGE;
+        uint32_t made = 0;
+        pq_dict_copy c{0, 0, 0};
+        const int st = pq_chunk_page_descs(&chunks[i], infos + chunks[i].info_first, np, layout, descs + out, &made,
+                                           &c.src, &c.dst, &c.bytes);
+        if (st != PQ_OK) return st;
+        out += made;
+        if (c.bytes) copies[nc++] = c;
+    }
+    first_desc[n_chunks] = (uint32_t)out;
+    *n_copies = nc;
+    return PQ_OK;
+}
+
 // ---- level post-processing ----------------------------------------------------
 
 static int ensure_work(pq_ctx *ctx, size_t bytes)

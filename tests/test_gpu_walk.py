@@ -148,6 +148,13 @@ def test_pyarrow_file_end_to_end(ctx, tmp_path, version, page_size):
         if dbytes:
             dict_copies.append((dsrc, ddst, dbytes))
     descs = np.array(all_descs, dtype=K.DESC_DTYPE)
+    # the one-call form builds the same table
+    layout2 = np.zeros(1, dtype=K.CHUNK_LAYOUT_DTYPE)
+    layout2["delta_ba_room"] = 1 << 18
+    descs2, first2, copies2 = capi.chunks_page_descs(chunks, res, infos, layout2)
+    assert descs2.tobytes() == descs.tobytes() and layout2.tobytes() == layout.tobytes()
+    assert [int(first2[i]) for i in range(len(recs))] == [s0 for s0, _ in spans] and int(first2[-1]) == len(descs)
+    assert [(int(c["src"]), int(c["dst"]), int(c["bytes"])) for c in copies2] == dict_copies
     vb, lb, db = int(layout["values_off"][0]) + 64, int(layout["levels_off"][0]) + 64, int(layout["dict_off"][0]) + 64
     t_val = torch.full((vb,), 0xA5, dtype=torch.uint8, device=dev)
     t_lvl = torch.full((lb,), 0xA5, dtype=torch.uint8, device=dev)

@@ -121,16 +121,10 @@ def main():
 
     def plan_chunks(res, infos):
         layout = np.zeros(1, dtype=capi.CHUNK_LAYOUT_DTYPE)
-        all_descs, spans, copies, total = [], [], [], 0
-        for i in range(len(recs)):
-            got = infos[i * cap: i * cap + int(res[i]["n_pages"])]
-            descs, dsrc, ddst, dbytes = capi.chunk_page_descs(chunks[i], got, layout)
-            spans.append((total, len(descs)))
-            total += len(descs)
-            all_descs.append(descs)
-            if dbytes:
-                copies.append((dsrc, ddst, dbytes))
-        return np.concatenate(all_descs), spans, copies, layout
+        descs, first, cps = capi.chunks_page_descs(chunks, res, infos, layout)
+        spans = [(int(first[i]), int(first[i + 1] - first[i])) for i in range(len(recs))]
+        copies = [(int(c["src"]), int(c["dst"]), int(c["bytes"])) for c in cps]
+        return descs, spans, copies, layout
 
     def wall(fn, reps):
         fn()
