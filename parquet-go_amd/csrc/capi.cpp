@@ -418,14 +418,24 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
         all.insert(all.end(), ids[g].begin(), ids[g].end());
     }
     if (n_pages) {
-        hipError_t e = hipMalloc((void **)&plan->d_descs, n_pages * sizeof(pq_page_desc));
-        if (e == hipSuccess) e = hipMalloc((void **)&plan->d_ids, n_pages * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void **)&plan->d_results, n_pages * sizeof(pq_page_result));
-        if (e == hipSuccess) e = hipMalloc((void **)&plan->d_flags, 256);
-        if (e == hipSuccess) e = hipMemset(plan->d_flags, 0, 256);
+        // one block: descriptors | results | ids | wake-up words (uint32 [0], [32], [64], each on a
+        // 128-byte line of its own)
+        constexpr size_t kFlagBytes = 512;
+        const size_t db = n_pages * sizeof(pq_page_desc), rb = n_pages * sizeof(pq_page_result);
+        const size_t ib = (n_pages * sizeof(uint32_t) + 255) / 256 * 256;
+        const size_t total = db + rb + ib + kFlagBytes;
+        uint8_t *block = nullptr;
+        hipError_t e = hipMalloc((void **)&block, total);
+        if (e == hipSuccess) {
+            plan->d_descs = reinterpret_cast<pq_page_desc *>(block);
+            plan->d_results = reinterpret_cast<pq_page_result *>(block + db);
+            plan->d_ids = reinterpret_cast<uint32_t *>(block + db + rb);
+            plan->d_flags = reinterpret_cast<uint32_t *>(block + db + rb + ib);
+            e = hipMemset(plan->d_ids, 0, ib + kFlagBytes);
+        }
         // synchronous copies: the host vectors die with this call
         if (e == hipSuccess)
-            e = hipMemcpy(plan->d_descs, descs, n_pages * sizeof(pq_page_desc), hipMemcpyHostToDevice);
+            e = hipMemcpy(plan->d_descs, descs, db, hipMemcpyHostToDevice);
         if (e == hipSuccess)
             e = hipMemcpy(plan->d_ids, all.data(), n_pages * sizeof(uint32_t), hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemset(plan->d_results, 0xff, n_pages * sizeof(pq_page_result));
@@ -444,10 +454,7 @@ void pq_plan_destroy(pq_plan *plan)
     if (!plan) return;
     (void)hipSetDevice(plan->ctx->device);
     (void)hipStreamSynchronize(plan->ctx->stream);
-    if (plan->d_descs) (void)hipFree(plan->d_descs);
-    if (plan->d_ids) (void)hipFree(plan->d_ids);
-    if (plan->d_results) (void)hipFree(plan->d_results);
-    if (plan->d_flags) (void)hipFree(plan->d_flags);
+    if (plan->d_descs) (void)hipFree(plan->d_descs);  // one block holds ids, results and flags too
     delete plan;
 }
 
