@@ -113,6 +113,12 @@ __device__ __forceinline__ bool wk_advance(WalkReader &r, uint64_t n)
 // readVarint64: up to the first byte without the continuation bit, bits past 64 dropped
 __device__ __forceinline__ bool wk_varint(WalkReader &r, uint64_t *out)
 {
+    if (r.have != 0u && ((uint32_t)r.buf & 0x80u) == 0u) {  // one byte, already in the register buffer: the usual case
+        *out = (uint32_t)r.buf & 0x7fu;
+        r.buf >>= 8;
+        r.have -= 1u;
+        return true;
+    }
     uint64_t v = 0;
     uint32_t shift = 0, b;
     while (true) {
