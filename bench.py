@@ -251,7 +251,7 @@ def main():
             "host_to_host": {"GBps_output": round(out_bytes / e2e / 1e9, 2),
                              "note": "one pass incl. H2D of pages and D2H of values, pinned host memory"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU figure is taken once, on the single-GPU run
             line["cpu_baseline"] = cpu_baseline(src, offs, lens, n, args.cpu_seconds)
         print(json.dumps(line), flush=True)
 
