@@ -230,3 +230,26 @@ def test_many_pages_of_strings(ctx):
         assert c.result["status"] == K.OK and c.result["n_decoded"] == 2000
         assert np.array_equal(c.ba_offsets, offs) and np.array_equal(c.ba_data[:room], flat)
         assert guard_ok(c.guard) and guard_ok(c.area_guard)
+
+
+def test_values_of_megabytes(ctx):
+    """A few very long values among short ones: the value-by-value path, offsets beyond 2^24."""
+    rng = np.random.default_rng(19)
+    vals = []
+    for i in range(130):
+        if i in (3, 64, 65, 129):
+            vals.append(bytes(rng.integers(0, 256, size=int(rng.integers(1 << 20, 3 << 20)), dtype=np.uint8)))
+        elif i in (4, 66):
+            vals.append(vals[-1][: 1 << 19] + b"tail")          # a long shared prefix
+        else:
+            vals.append(bytes(rng.integers(0, 256, size=int(rng.integers(0, 30)), dtype=np.uint8)))
+    room = total_len(vals)
+    flat = np.frombuffer(b"".join(vals), dtype=np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(v) for v in vals])]).astype(np.uint32)
+    cases = [_case(K.KIND_DELTA_LENGTH_BA, synth.delta_length_ba_encode(vals), 130),
+             _case(K.KIND_DELTA_BA, synth.delta_ba_encode(vals), 130, data_cap=room)]
+    run_cases(ctx, cases, seed=11)
+    for c in cases:
+        assert c.result["status"] == K.OK and c.result["n_decoded"] == 130
+        assert np.array_equal(c.ba_offsets[:131], offs) and np.array_equal(c.ba_data[:room], flat)
+        assert guard_ok(c.guard) and guard_ok(c.area_guard)

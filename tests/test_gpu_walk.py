@@ -104,6 +104,19 @@ def test_fuzzed_headers(ctx):
     _compare(ctx, cases)
 
 
+def test_unknown_fields_of_every_shape(ctx):
+    """thrift.Skip over random nested structs, lists, sets and maps, whole and cut short."""
+    rng = np.random.default_rng(24)
+    chunks = W.chunks_with_unknown_fields(rng, 400)
+    cut = []
+    for c in chunks[:150]:
+        for _ in range(4):
+            d = dict(c)
+            d["src"] = c["src"][: int(rng.integers(0, c["src"].size))].copy()
+            cut.append(d)
+    _compare(ctx, chunks + cut)
+
+
 @pytest.mark.parametrize("version,page_size", [("1.0", 1 << 30), ("2.0", 4000), ("1.0", 4000)])
 def test_pyarrow_file_end_to_end(ctx, tmp_path, version, page_size):
     import torch

@@ -129,3 +129,11 @@ def test_pyarrow_files_walk_and_decode(tmp_path, version, page_size):
             assert np.array_equal(got.view(np.uint8), np.ascontiguousarray(want_vals).view(np.uint8)), rec["name"]
         if want_def is not None:
             assert np.array_equal(np.concatenate(defs), want_def) and np.array_equal(np.concatenate(reps), want_rep)
+
+
+def test_unknown_fields_of_every_shape_are_stepped_over():
+    rng = np.random.default_rng(24)
+    for c in W.chunks_with_unknown_fields(rng, 300):
+        r = _walk(c)
+        assert r["status"] == O.OK and len(r["infos"]) == 2 and r["count"] == c["src"].size
+        assert r["infos"]["num_values"].tolist() == [8, 4]

@@ -130,3 +130,67 @@ def truncations(c, step=1):
         d = dict(c)
         d["src"] = c["src"][:cut].copy()
         yield d
+
+
+SCALARS = ["i32", "i64", "i16", "byte", "double", "binary", "bool"]
+
+
+def random_kind(rng, depth):
+    """A random Thrift kind as parquet_go_amd.synth.thrift_value names it; containers up to six deep."""
+    kinds = list(SCALARS)
+    if depth < 6:
+        kinds += ["struct", "list", "set", "map"] * 2
+    k = kinds[int(rng.integers(0, len(kinds)))]
+    if k in ("list", "set"):
+        return (k, SCALARS[int(rng.integers(0, 7))] if rng.random() < 0.6 else "struct")
+    if k == "map":
+        return ("map", ["i32", "i64", "binary", "byte"][int(rng.integers(0, 4))],
+                ["i32", "binary", "struct", "double"][int(rng.integers(0, 4))])
+    return k
+
+
+def random_value(rng, kind, depth):
+    """A value of the given kind: what the skip of an unknown field has to step over."""
+    if kind in ("i32", "i16"):
+        return int(rng.integers(-2**15, 2**15))
+    if kind == "i64":
+        return int(rng.integers(-2**62, 2**62))
+    if kind == "byte":
+        return int(rng.integers(0, 256))
+    if kind == "double":
+        return float(rng.random())
+    if kind == "binary":
+        return bytes(rng.integers(0, 256, size=int(rng.integers(0, 40)), dtype=np.uint8))
+    if kind == "bool":
+        return bool(rng.integers(0, 2))
+    if kind == "struct":
+        fields, fid = [], 0
+        for _ in range(int(rng.integers(0, 5))):
+            fid += int(rng.integers(1, 40))
+            k = random_kind(rng, depth + 1)
+            fields.append((fid, k, random_value(rng, k, depth + 1)))
+        return fields
+    if kind[0] in ("list", "set"):
+        return [random_value(rng, kind[1], depth + 1) for _ in range(int(rng.integers(0, 20)))]
+    return [(random_value(rng, kind[1], depth + 1), random_value(rng, kind[2], depth + 1))
+            for _ in range(int(rng.integers(0, 6)))]
+
+
+def random_thrift_value(rng, depth=0):
+    k = random_kind(rng, depth)
+    return k, random_value(rng, k, depth)
+
+
+def chunks_with_unknown_fields(rng, count):
+    """Well-formed V1 chunks whose headers carry random unknown fields at every level."""
+    out = []
+    for _ in range(count):
+        extra, fid = [], 8
+        for _ in range(int(rng.integers(1, 4))):
+            fid += int(rng.integers(1, 30))
+            k, v = random_thrift_value(rng)
+            extra.append((fid, k, v))
+        stats = [(int(rng.integers(7, 20)), *random_thrift_value(rng))]
+        h = synth.page_header(0, 32, 32, data=(8, 0, RLE, RLE, stats), extra=extra)
+        out.append(chunk([(h, 32), (synth.page_header(0, 16, 16, data=(4, 0, RLE, RLE)), 16)]))
+    return out
