@@ -339,6 +339,164 @@ __device__ __forceinline__ bool wk_page_header(WalkReader &r, PageHeader &h)
     return (isset & 0x0eu) == 0x0eu;
 }
 
+// ---- the header shapes every writer emits, as straight-line code ------------------------------
+//
+// A single wave pays for every taken branch, and the general reader above is nothing but
+// branches.  Real headers are far more regular than the protocol allows: fields in id order with
+// one-byte field headers, i32 values of at most four varint bytes, and at the end of the page-
+// type header an optional Statistics struct of binaries, i64 counts and booleans.  The fast path takes
+// exactly those (anything else — long-form field ids, unknown fields, collections, a crc that
+// needs five varint bytes, a header that leaves the staged window — makes it step back, having
+// changed nothing, and the general reader parses the header from its first byte).  What it
+// accepts it decodes to the same PageHeader the general reader would.
+//
+// Bytes come from a VGPR that holds 256 bytes of the LDS window, one dword per lane: eight bytes
+// at any offset are three v_readlane and two shifts, with no trip to LDS and nothing to wait for.
+struct FastWin {
+    uint32_t v;     // lane k: dword k of the window from byte offset `base` on
+    uint32_t base;  // a multiple of 4
+};
+
+__device__ __forceinline__ void fw_load(FastWin &f, const WalkReader &r, uint32_t o)
+{
+    f.base = o & ~3u;
+    f.v = r.lds[(f.base >> 2) + (uint32_t)r.lane];  // the window array has 64 words of slack behind it
+}
+
+// eight window bytes from offset o on (lowest first)
+__device__ __forceinline__ uint64_t fw_get(FastWin &f, const WalkReader &r, uint32_t o)
+{
+    if (o < f.base || o + 12u > f.base + 256u) fw_load(f, r, o);
+    const uint32_t i = (o - f.base) >> 2, sh = (o & 3u) * 8u;
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)f.v, (int)i);
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)f.v, (int)(i + 1u));
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)f.v, (int)(i + 2u));
+    const uint32_t lo = (uint32_t)(((((uint64_t)b) << 32) | a) >> sh);
+    const uint32_t hi = (uint32_t)(((((uint64_t)c) << 32) | b) >> sh);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// A varint of 1..4 bytes in the low bytes of x: its value and length (0: it is longer).
+__device__ __forceinline__ uint32_t fw_varint(uint32_t x, uint32_t *value)
+{
+    const uint32_t stop = ~x & 0x80808080u;
+    if (stop == 0u) return 0u;
+    const uint32_t vl = ((uint32_t)__builtin_ctz(stop) + 1u) >> 3;
+    x &= 0xffffffffu >> (32u - 8u * vl);
+    *value = (x & 0x7fu) | ((x >> 1) & 0x3f80u) | ((x >> 2) & 0x1fc000u) | ((x >> 3) & 0xfe00000u);
+    return vl;
+}
+
+// Field header byte `hdr` followed by an i32 (zig-zag varint): false when the bytes say otherwise.
+__device__ __forceinline__ bool fw_i32(FastWin &f, const WalkReader &r, uint32_t &o, uint32_t hdr, int32_t *out)
+{
+    const uint64_t g = fw_get(f, r, o);
+    uint32_t u = 0;
+    const uint32_t vl = fw_varint((uint32_t)(g >> 8), &u);
+    if (((uint32_t)g & 255u) != hdr || vl == 0u) return false;
+    *out = (int32_t)((u >> 1) ^ (0u - (u & 1u)));
+    o += 1u + vl;
+    return true;
+}
+
+// `count` i32 fields with ids 1, 2, 3 ... into h.f[1 ..]
+__device__ __forceinline__ bool fw_i32_run(FastWin &f, const WalkReader &r, uint32_t &o, SubHeader &h, uint32_t count)
+{
+    bool ok = true;
+#pragma unroll
+    for (uint32_t k = 1; k <= 6u; ++k) {
+        if (k <= count) {
+            int32_t v = 0;
+            ok = ok && fw_i32(f, r, o, 0x15u, &v);
+            h.f[k] = v;
+        }
+    }
+    h.isset = (2u << count) - 2u;
+    h.present = 1;
+    return ok;
+}
+
+// An optional Statistics struct (field header `hdr`) and the stop byte of the struct around it.
+// Binaries, i64 counts and booleans with one-byte field headers only; `lim` = window bytes inside the stream.
+__device__ __forceinline__ bool fw_statistics_and_stop(FastWin &f, const WalkReader &r, uint32_t &o, uint32_t hdr,
+                                                       uint32_t lim)
+{
+    uint64_t g = fw_get(f, r, o);
+    if (((uint32_t)g & 255u) == hdr) {
+        o += 1u;
+        for (int k = 0; k < 10; ++k) {  // Statistics has eight fields: four binaries, two counts, two booleans
+            if (o + 12u > lim) return false;
+            g = fw_get(f, r, o);
+            const uint32_t b = (uint32_t)g & 255u;
+            if (b == 0u) break;
+            uint32_t u = 0;
+            const uint32_t vl = fw_varint((uint32_t)(g >> 8), &u);
+            const uint32_t t = b & 15u;
+            const bool flag = t == CT_TRUE || t == CT_FALSE;  // a boolean field is its header byte
+            if ((b >> 4) == 0u || (!flag && (vl == 0u || (t != CT_BINARY && t != CT_I64)))) return false;
+            o += flag ? 1u : 1u + vl + (t == CT_BINARY ? u : 0u);
+        }
+        if (o + 12u > lim) return false;
+        g = fw_get(f, r, o);
+        if (((uint32_t)g & 255u) != 0u) return false;  // more than the loop allows, or not the struct's end
+        o += 1u;
+        g = fw_get(f, r, o);
+    }
+    if (((uint32_t)g & 255u) != 0u) return false;
+    o += 1u;
+    return true;
+}
+
+// true: the header at the read position was one of the usual shapes; h is filled and the reader
+// stands behind it.  false: nothing changed.
+__device__ __forceinline__ bool wk_fast_header(WalkReader &r, PageHeader &h)
+{
+    const int64_t pos = wk_pos(r);
+    if (pos >= r.len) return false;
+    if (pos < r.c0 || pos + 64 > r.c0 + kWkWin) wk_stage(r, pos);
+    const int64_t left = r.len - r.c0;
+    const uint32_t lim = left < (int64_t)kWkWin ? (uint32_t)left : (uint32_t)kWkWin;  // staged bytes inside the stream
+    uint32_t o = (uint32_t)(pos - r.c0);
+    if (o + 64u > lim) return false;  // a header this close to the end goes the careful way
+    FastWin f;
+    fw_load(f, r, o);
+    h.type = h.uncompressed = h.compressed = 0;
+    wk_clear(h.data);
+    wk_clear(h.dict);
+    wk_clear(h.v2);
+    if (!fw_i32(f, r, o, 0x15u, &h.type) || !fw_i32(f, r, o, 0x15u, &h.uncompressed) ||
+        !fw_i32(f, r, o, 0x15u, &h.compressed))
+        return false;
+    const uint32_t b = (uint32_t)fw_get(f, r, o) & 255u;
+    o += 1u;
+    bool ok;
+    if (b == 0x2cu) {  // field 5: DataPageHeader
+        ok = fw_i32_run(f, r, o, h.data, 4u) && fw_statistics_and_stop(f, r, o, 0x1cu, lim);
+    } else if (b == 0x4cu) {  // field 7: DictionaryPageHeader, is_sorted optional
+        ok = fw_i32_run(f, r, o, h.dict, 2u);
+        const uint32_t s = (uint32_t)fw_get(f, r, o) & 255u;
+        if (s == 0x11u || s == 0x12u) o += 1u;
+        ok = ok && ((uint32_t)fw_get(f, r, o) & 255u) == 0u;
+        o += 1u;
+    } else if (b == 0x5cu) {  // field 8: DataPageHeaderV2, is_compressed optional
+        ok = fw_i32_run(f, r, o, h.v2, 6u);
+        const uint32_t s = (uint32_t)fw_get(f, r, o) & 255u;
+        uint32_t stats_hdr = 0x2cu;  // Statistics is field 8: two past field 6 ...
+        if (s == 0x11u || s == 0x12u) {
+            h.v2.is_compressed = s == 0x11u ? 1u : 0u;
+            o += 1u;
+            stats_hdr = 0x1cu;  // ... one past field 7
+        }
+        ok = ok && fw_statistics_and_stop(f, r, o, stats_hdr, lim);
+    } else {
+        return false;
+    }
+    if (!ok || o + 1u > lim || ((uint32_t)fw_get(f, r, o) & 255u) != 0u) return false;  // the PageHeader's stop
+    o += 1u;
+    wk_seek(r, r.c0 + (int64_t)o);
+    return true;
+}
+
 // getValuesDecoder (layout/page-dict.go:143-345)
 __device__ __forceinline__ bool wk_decoder_exists(uint32_t type, int32_t type_length, int32_t enc)
 {
@@ -375,7 +533,7 @@ __global__ __launch_bounds__(kWkWaves *kWave) void walk_chunks_kernel(const pq_c
                                                                      pq_page_info *__restrict__ infos,
                                                                      pq_chunk_result *__restrict__ results)
 {
-    __shared__ uint32_t s_win[kWkWaves][kWkWin / 4 + 4];
+    __shared__ uint32_t s_win[kWkWaves][kWkWin / 4 + 64];  // slack: the fast path loads 64 dwords from any window offset
     __shared__ uint32_t s_frames[kWkWaves][2 * kWkDepth];
     const int wave = (int)uni(threadIdx.x / kWave), lane = (int)(threadIdx.x % kWave);
     const uint32_t ci = blockIdx.x * kWkWaves + (uint32_t)wave;
@@ -403,7 +561,7 @@ __global__ __launch_bounds__(kWkWaves *kWave) void walk_chunks_kernel(const pq_c
         if (c.total_compressed_size - count < 1) break;  // chunk.go:136
         const int64_t h0 = wk_pos(r);
         PageHeader h;
-        if (!wk_page_header(r, h)) {
+        if (!wk_fast_header(r, h) && !wk_page_header(r, h)) {
             st = PQ_WALK_HEADER_FAILED;
             count += wk_pos(r) - h0;
             break;

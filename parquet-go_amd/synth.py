@@ -355,7 +355,7 @@ def statistics(rng=None):
     return [(1, "binary", bytes(rng.integers(0, 256, size=int(rng.integers(0, 40)), dtype=np.uint8))),
             (2, "binary", b"ab"), (3, "i64", int(rng.integers(0, 1000))), (4, "i64", 77),
             (5, "binary", bytes(rng.integers(0, 256, size=int(rng.integers(0, 200)), dtype=np.uint8))),
-            (6, "binary", b"")]
+            (6, "binary", b""), (7, "bool", True), (8, "bool", False)]
 
 
 def page_header(page_type, uncompressed, compressed, data=None, dictionary=None, v2=None, crc=None, extra=()):
