@@ -255,7 +255,11 @@ __device__ __forceinline__ ByteArrayResult delta_length_ba_wave(uint32_t *window
 // 64 values (one per lane) finds that k with one ballot per byte position; positions no value of
 // the batch starts a suffix at come from the batch in front (its last value, already in `data`).
 
-constexpr uint32_t kBaBatchMaxLen = 192;  // batches with a longer value go value by value
+constexpr uint32_t kBaOutWin = 2048;           // bytes of the output a wave keeps in LDS (a power of two)
+constexpr uint32_t kBaSufWin = kBaOutWin + 16;  // a batch's suffix bytes, from a 16-byte boundary
+constexpr uint32_t kBaPrefixCols = 4;          // byte positions per step of the column loops: their LDS reads go
+constexpr uint32_t kBaCols = 8;                // out together, but every position of a step is paid for
+constexpr uint32_t kBaLdsBytes = kBaOutWin + kBaSufWin;
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
 {
@@ -375,79 +379,163 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
     done = res.n_decoded;
 
     // ---- pass B: the bytes ----
+    // Batches of up to 64 values (one per lane) are put together in LDS: the batch's suffix bytes
+    // are staged with 16-byte loads, every byte of a value finds its suffix there (or in the value
+    // in front of the batch, which the output window still holds), and whole 16-byte pieces of the
+    // output window go to memory.  The window is circular, indexed by the low bits of the output
+    // ADDRESS, so a 16-byte piece of memory is a 16-byte piece of LDS and nothing is ever moved.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const uint8_t *SUF = S + init_consumed;
-    uint8_t *prev = reinterpret_cast<uint8_t *>(window);  // the value in front of the batch (the lengths are done with the window)
+    uint8_t *obuf = reinterpret_cast<uint8_t *>(window);  // the lengths are done with the window
+    uint8_t *sbuf = obuf + kBaOutWin;
+    const uint32_t dlow = (uint32_t)reinterpret_cast<uintptr_t>(data);
+    const uint64_t below = (2ull << lane) - 1ull;
     bool prev_in_lds = false;
-    uint32_t sc = 0;        // suffix bytes in front of this batch
-    uint32_t prev_off = 0;  // offset of the value in front of this batch
-    for (uint32_t base = 0; base < done; base += kWave) {
-        const uint32_t i = base + (uint32_t)lane;
-        const bool live = i < done;
-        const uint32_t o0 = live ? __hip_atomic_load(area + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        const uint32_t o1 = live ? __hip_atomic_load(area + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        const int32_t pr = live ? (int32_t)P[i] : 0;
-        const uint32_t p = live ? (pr > 0 ? (uint32_t)pr : 0u) : 0x7fffffffu;
-        const uint32_t vlen = o1 - o0;
-        const uint32_t s = live ? vlen - p : 0u;
-        const uint32_t sincl = sc + wave_scan_u32(s);
-        const uint32_t soff = sincl - s;
-        const uint32_t maxlen = wave_max_u32(vlen);
-        const uint32_t nlive = min((uint32_t)kWave, done - base);
-        if (maxlen <= kBaBatchMaxLen) {
-            const uint32_t srcbase = soff - p;  // suffix-area offset of this value's position 0
-            const uint64_t below = (2ull << lane) - 1ull;
-            const bool is_last = (uint32_t)lane == nlive - 1u;
-            for (uint32_t j0 = 0; j0 < maxlen; j0 += 4u) {
-                uint8_t got[4];
-                // four positions' loads go out together
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    const uint32_t j = j0 + u;
-                    const uint64_t mk = __builtin_amdgcn_ballot_w64(p <= j) & below;
-                    const bool has = mk != 0ull;
-                    const int k = has ? 63 - __builtin_clzll(mk) : 0;
-                    const uint32_t sb = (uint32_t)__shfl((int)srcbase, k);
-                    uint8_t b = 0;
-                    if (j < vlen) {
-                        if (has)
-                            b = SUF[(uint32_t)(sb + j)];
-                        else if (prev_in_lds)
-                            b = prev[j];
-                        else
-                            b = data[prev_off + j];
-                    }
-                    got[u] = b;
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    const uint32_t j = j0 + u;
-                    if (j < vlen) {
-                        data[o0 + j] = got[u];
-                        if (is_last) prev[j] = got[u];
-                    }
-                }
+    uint32_t sc = 0;       // suffix bytes in front of this batch
+    uint32_t o_prev = 0;   // offset of the value in front of this batch
+    uint32_t flushed = 0;  // data[0, flushed) is in memory; [flushed, batch start) waits in the window
+    uint32_t base = 0;
+    // lengths of the 64 values from b on; the next batch's are asked for while this one's suffix
+    // bytes are on their way
+    auto load_lens = [&](uint32_t b, uint32_t &a0, uint32_t &a1, int32_t &ap) {
+        const uint32_t i = b + (uint32_t)lane;
+        const bool in = i < done;
+        a0 = in ? __hip_atomic_load(area + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        a1 = in ? __hip_atomic_load(area + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        ap = in ? (int32_t)P[i] : 0;
+    };
+    uint32_t o0, o1;
+    int32_t pr;
+    load_lens(0, o0, o1, pr);
+    while (base < done) {
+        const bool in_range = base + (uint32_t)lane < done;
+        const uint32_t o_start = uni(o0);
+        const uint32_t ws = min(prev_in_lds ? o_prev : o_start, flushed);  // the window has to hold [ws, batch end)
+        const uint64_t fits = __builtin_amdgcn_ballot_w64(in_range && o1 - ws <= kBaOutWin);
+        const uint32_t nb = ~fits ? (uint32_t)__builtin_ctzll(~fits) : (uint32_t)kWave;
+        if (nb == 0u || (base != 0u && !prev_in_lds)) {
+            // a value the window cannot hold next to the one in front of it, or whose predecessor
+            // the window does not hold: straight through memory
+            const uint32_t pend = o_start - flushed;  // < 16 bytes of the batch in front
+            if ((uint32_t)lane < pend) data[flushed + lane] = obuf[(dlow + flushed + (uint32_t)lane) & (kBaOutWin - 1u)];
+            const uint32_t vl = uni(o1) - o_start;
+            const uint32_t pl = uni(pr > 0 ? (uint32_t)pr : 0u);
+            if (pl > 0u) {
+                workgroup_fence();  // the value in front has to be in memory
+                wave_copy_bytes(data + o_start, data + o_prev, pl, lane);
             }
-            prev_in_lds = true;
-        } else {
-            for (uint32_t l = 0; l < nlive; ++l) {
-                const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)l);
-                const uint32_t vl = (uint32_t)__builtin_amdgcn_readlane((int)vlen, (int)l);
-                const uint32_t ol = (uint32_t)__builtin_amdgcn_readlane((int)o0, (int)l);
-                const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)soff, (int)l);
-                const uint32_t before = l ? (uint32_t)__builtin_amdgcn_readlane((int)o0, (int)(l - 1u)) : prev_off;
-                if (pl > 0u) {
-                    workgroup_fence();  // the value in front has to be in memory
-                    for (uint32_t j = (uint32_t)lane; j < pl; j += kWave) data[ol + j] = data[before + j];
-                }
-                for (uint32_t j = (uint32_t)lane; j < vl - pl; j += kWave) data[ol + pl + j] = SUF[sl + j];
-            }
+            wave_copy_bytes(data + o_start + pl, SUF + sc, vl - pl, lane);
             workgroup_fence();
-            prev_in_lds = false;
+            prev_in_lds = vl <= kBaOutWin;
+            if (prev_in_lds) {  // back into the window, for the batch behind it
+                for (uint32_t j = (uint32_t)lane; j < vl; j += kWave)
+                    obuf[(dlow + o_start + j) & (kBaOutWin - 1u)] = data[o_start + j];
+                wave_sync();
+            }
+            o_prev = o_start;
+            flushed = o_start + vl;
+            sc += vl - pl;
+            base += 1u;
+            load_lens(base, o0, o1, pr);
+            continue;
         }
-        prev_off = (uint32_t)__builtin_amdgcn_readlane((int)o0, (int)(nlive - 1u));
-        sc = wave_last_u32(sincl);
+        const bool live = (uint32_t)lane < nb;
+        const uint32_t p = live ? (pr > 0 ? (uint32_t)pr : 0u) : 0x7fffffffu;
+        const uint32_t vlen = live ? o1 - o0 : 0u;
+        const uint32_t s = live ? vlen - p : 0u;
+        const uint32_t sincl = wave_scan_u32(s);
+        const uint32_t stot = wave_last_u32(sincl);
+        const uint32_t o_end = (uint32_t)__builtin_amdgcn_readlane((int)o1, (int)(nb - 1u));
+
+        // the batch's suffix bytes: every 16-byte piece of the stream's buffer that holds one
+        const uintptr_t sa = reinterpret_cast<uintptr_t>(SUF) + sc;
+        const uint32_t shift = (uint32_t)(sa & 15u);
+        const u32x4_t *s16 = reinterpret_cast<const u32x4_t *>(sa - shift);
+        const uint32_t spieces = stot ? (shift + stot + 15u) >> 4 : 0u;  // <= (15 + 2048 + 15) / 16
+        u32x4_t sv[3];
+#pragma unroll
+        for (uint32_t u = 0; u < 3u; ++u) {
+            const uint32_t q = (uint32_t)lane + kWave * u;
+            if (q < spieces) sv[u] = __builtin_nontemporal_load(s16 + q);
+        }
+        uint32_t n0, n1;
+        int32_t np;
+        load_lens(base + nb, n0, n1, np);
+#pragma unroll
+        for (uint32_t u = 0; u < 3u; ++u) {
+            const uint32_t q = (uint32_t)lane + kWave * u;
+            if (q < spieces) reinterpret_cast<u32x4_t *>(sbuf)[q] = sv[u];
+        }
+        wave_sync();
+
+        const uint32_t srcb = shift + (sincl - s);       // sbuf index of this value's suffix (sbuf = obuf + kBaOutWin)
+        const uint32_t srcp = srcb - p;                  // ... of its position 0, were the suffix the whole value
+        const uint32_t ob = dlow + o0;                   // window index (mod its size) of the value's position 0
+        const uint32_t pb = dlow + o_prev;               // ... of the value in front of the batch
+        // positions in front of the suffix: the nearest value at or below this one that starts
+        // its suffix at or before position j supplies the byte
+        for (uint32_t j0 = 0; __builtin_amdgcn_ballot_w64(live && j0 < p) != 0ull; j0 += kBaPrefixCols) {
+            uint8_t got[kBaPrefixCols];
+#pragma unroll
+            for (uint32_t u = 0; u < kBaPrefixCols; ++u) {
+                const uint32_t j = j0 + u;
+                const uint64_t mk = __builtin_amdgcn_ballot_w64(p <= j) & below;
+                const bool has = mk != 0ull;
+                const int k = has ? 63 - __builtin_clzll(mk) : 0;
+                const uint32_t sb = (uint32_t)__shfl((int)srcp, k);
+                // one LDS read either way: the staged suffix, or the value in front of the batch
+                const uint32_t at = has ? kBaOutWin + sb + j : (pb + j) & (kBaOutWin - 1u);
+                const uint8_t b = obuf[live && j < p ? at : 0u];
+                got[u] = b;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kBaPrefixCols; ++u) {
+                const uint32_t j = j0 + u;
+                if (live && j < p) obuf[(ob + j) & (kBaOutWin - 1u)] = got[u];
+            }
+        }
+        // the value's own suffix
+        const uint32_t os = ob + p;
+        for (uint32_t t0 = 0; __builtin_amdgcn_ballot_w64(t0 < s) != 0ull; t0 += kBaCols) {
+            uint8_t got[kBaCols];
+#pragma unroll
+            for (uint32_t u = 0; u < kBaCols; ++u) got[u] = t0 + u < s ? sbuf[srcb + t0 + u] : (uint8_t)0;
+#pragma unroll
+            for (uint32_t u = 0; u < kBaCols; ++u)
+                if (t0 + u < s) obuf[(os + t0 + u) & (kBaOutWin - 1u)] = got[u];
+        }
+        wave_sync();
+
+        // whole 16-byte pieces of [flushed, o_end) go to memory; the rest waits for the next batch
+        const bool last = base + nb >= done;
+        uint32_t f = flushed;
+        const uint32_t head = min((16u - ((dlow + f) & 15u)) & 15u, o_end - f);
+        if ((uint32_t)lane < head) data[f + lane] = obuf[(dlow + f + (uint32_t)lane) & (kBaOutWin - 1u)];
+        f += head;
+        const uint32_t opieces = (o_end - f) >> 4;  // <= 128
+#pragma unroll
+        for (uint32_t u = 0; u < 2u; ++u) {
+            const uint32_t q = (uint32_t)lane + kWave * u;
+            if (q < opieces) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t *>(obuf + ((dlow + f + 16u * q) & (kBaOutWin - 1u)));
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(data + f) + q);
+            }
+        }
+        f += 16u * opieces;
+        if (last) {
+            const uint32_t tail = o_end - f;
+            if ((uint32_t)lane < tail) data[f + lane] = obuf[(dlow + f + (uint32_t)lane) & (kBaOutWin - 1u)];
+            f = o_end;
+        }
+        flushed = f;
+        o_prev = (uint32_t)__builtin_amdgcn_readlane((int)o0, (int)(nb - 1u));
+        prev_in_lds = true;
+        sc += stot;
+        base += nb;
+        o0 = n0;
+        o1 = n1;
+        pr = np;
     }
     return res;
 }

@@ -169,6 +169,10 @@ __device__ __forceinline__ HybridResult dict_values(HybridShared &sh, const uint
 
 // DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY in the workgroup-per-stream kernels: the first wave
 // does it alone, in the staging window of the hybrid decoder.
+static_assert(sizeof(HybridWaveLds) >= kBaLdsBytes && sizeof(HybridShared::chunk) >= kBaLdsBytes,
+              "the byte-array decoder stages a batch in the LDS of the decoder it replaces");
+static_assert(offsetof(HybridWaveLds, window) == 0, "the byte-array decoder takes the whole struct as its window");
+
 __device__ __forceinline__ ByteArrayResult byte_array_wg(uint32_t kind, HybridShared &sh, const uint8_t *S, int64_t len,
                                                          uint32_t n, const pq_page_desc &d, uint8_t *values)
 {
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(kHwWG) void stream_wave_kernel(const pq_page_desc *
                 r.consumed = (uint64_t)len;
         }
     } else if (d.kind == PQ_KIND_DELTA_LENGTH_BA || d.kind == PQ_KIND_DELTA_BA) {
-        const ByteArrayResult br = byte_array_wave(d.kind, L.window, S, len, n, d, buf.values, lane);
+        const ByteArrayResult br = byte_array_wave(d.kind, reinterpret_cast<uint32_t *>(&L), S, len, n, d, buf.values, lane);
         r.status = br.status;
         r.n_decoded = br.n_decoded;
         r.consumed = br.consumed;
@@ -864,7 +868,7 @@ __global__ __launch_bounds__(kHwWG) void data_wave_kernel(const pq_page_desc *__
         v_status = vr.status;
         v_count = vr.n_decoded;
     } else if (d.value_kind == PQ_KIND_DELTA_LENGTH_BA || d.value_kind == PQ_KIND_DELTA_BA) {
-        const ByteArrayResult br = byte_array_wave(d.value_kind, L.window, VS, vlen, nvals, d, buf.values, lane);
+        const ByteArrayResult br = byte_array_wave(d.value_kind, reinterpret_cast<uint32_t *>(&L), VS, vlen, nvals, d, buf.values, lane);
         if (br.init_failed) v_init = br.status;
         v_status = br.status;
         v_count = br.n_decoded;

@@ -390,6 +390,8 @@ def main():
     if want("bytes"):
         bench_byte_array(ctx, stream, args.pages, 20000, False)
         bench_byte_array(ctx, stream, args.pages, 20000, True)
+    if args.only and want("dba"):      # DELTA_BYTE_ARRAY alone, for counter passes
+        bench_byte_array(ctx, stream, args.pages, 20000, True)
     if want("bytes_init"):
         bench_byte_array(ctx, stream, args.pages, 20000, False, pull=0)
         bench_byte_array(ctx, stream, args.pages, 20000, True, pull=0)
