@@ -28,12 +28,19 @@ struct pq_ctx {
     // grow-only scratch of the device-pointer entry points that need one
     void *work = nullptr;
     size_t work_cap = 0;
+    // plans: the device block of the last plan destroyed (the next one takes it if it is large
+    // enough) and a pinned host image the plan tables are put together in
+    void *spare_block = nullptr;
+    size_t spare_bytes = 0;
+    void *host_img = nullptr;
+    size_t host_img_cap = 0;
 };
 
 struct pq_plan {
     pq_ctx *ctx = nullptr;
     size_t n = 0;
     pq_page_desc *d_descs = nullptr;
+    size_t block_bytes = 0;  // of the device block d_descs starts
     uint32_t *d_ids = nullptr;
     pq_page_result *d_results = nullptr;
     uint32_t *d_flags = nullptr; // [0], [32], [64]: sweep wake-up words (delta32, delta64, data pages)
@@ -238,6 +245,8 @@ void pq_ctx_destroy(pq_ctx *ctx)
     for (int i = 0; i < 4; ++i)
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
     if (ctx->work) (void)hipFree(ctx->work);
+    if (ctx->spare_block) (void)hipFree(ctx->spare_block);
+    if (ctx->host_img) (void)hipHostFree(ctx->host_img);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -418,27 +427,48 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
         all.insert(all.end(), ids[g].begin(), ids[g].end());
     }
     if (n_pages) {
-        // one block: descriptors | results | ids | wake-up words (uint32 [0], [32], [64], each on a
-        // 128-byte line of its own)
+        // one block: descriptors | ids | wake-up words (uint32 [0], [32], [64], each on a 128-byte
+        // line of its own) | results.  Everything in front of the results is put together in a
+        // pinned host image and goes over in one copy.
         constexpr size_t kFlagBytes = 512;
-        const size_t db = n_pages * sizeof(pq_page_desc), rb = n_pages * sizeof(pq_page_result);
+        const size_t db = (n_pages * sizeof(pq_page_desc) + 255) / 256 * 256, rb = n_pages * sizeof(pq_page_result);
         const size_t ib = (n_pages * sizeof(uint32_t) + 255) / 256 * 256;
-        const size_t total = db + rb + ib + kFlagBytes;
+        const size_t img = db + ib + kFlagBytes, total = img + rb;
         uint8_t *block = nullptr;
-        hipError_t e = hipMalloc((void **)&block, total);
+        hipError_t e = hipSuccess;
+        if (ctx->spare_block && ctx->spare_bytes >= total) {
+            block = static_cast<uint8_t *>(ctx->spare_block);
+            plan->block_bytes = ctx->spare_bytes;
+            ctx->spare_block = nullptr;
+            ctx->spare_bytes = 0;
+        } else {
+            e = hipMalloc((void **)&block, total);
+            plan->block_bytes = total;
+        }
+        if (e == hipSuccess && ctx->host_img_cap < img) {
+            if (ctx->host_img) (void)hipHostFree(ctx->host_img);
+            ctx->host_img = nullptr;
+            ctx->host_img_cap = 0;
+            const size_t cap = img + img / 2;
+            e = hipHostMalloc(&ctx->host_img, cap, hipHostMallocDefault);
+            if (e == hipSuccess) ctx->host_img_cap = cap;
+        }
         if (e == hipSuccess) {
             plan->d_descs = reinterpret_cast<pq_page_desc *>(block);
-            plan->d_results = reinterpret_cast<pq_page_result *>(block + db);
-            plan->d_ids = reinterpret_cast<uint32_t *>(block + db + rb);
-            plan->d_flags = reinterpret_cast<uint32_t *>(block + db + rb + ib);
-            e = hipMemset(plan->d_ids, 0, ib + kFlagBytes);
+            plan->d_ids = reinterpret_cast<uint32_t *>(block + db);
+            plan->d_flags = reinterpret_cast<uint32_t *>(block + db + ib);
+            plan->d_results = reinterpret_cast<pq_page_result *>(block + img);
+            uint8_t *h = static_cast<uint8_t *>(ctx->host_img);
+            std::memcpy(h, descs, n_pages * sizeof(pq_page_desc));
+            std::memcpy(h + db, all.data(), n_pages * sizeof(uint32_t));
+            std::memset(h + db + n_pages * sizeof(uint32_t), 0, ib - n_pages * sizeof(uint32_t) + kFlagBytes);
+            e = hipMemcpyAsync(block, h, img, hipMemcpyHostToDevice, ctx->stream);
+        } else if (block) {
+            plan->d_descs = reinterpret_cast<pq_page_desc *>(block);  // for pq_plan_destroy
         }
-        // synchronous copies: the host vectors die with this call
-        if (e == hipSuccess)
-            e = hipMemcpy(plan->d_descs, descs, db, hipMemcpyHostToDevice);
-        if (e == hipSuccess)
-            e = hipMemcpy(plan->d_ids, all.data(), n_pages * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemset(plan->d_results, 0xff, n_pages * sizeof(pq_page_result));
+        if (e == hipSuccess) e = hipMemsetAsync(plan->d_results, 0xff, rb, ctx->stream);
+        // the image is the context's: the next plan may not overwrite it under a copy in flight
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             hip_ok(ctx, e, "pq_plan_create");
             pq_plan_destroy(plan);
@@ -454,7 +484,16 @@ void pq_plan_destroy(pq_plan *plan)
     if (!plan) return;
     (void)hipSetDevice(plan->ctx->device);
     (void)hipStreamSynchronize(plan->ctx->stream);
-    if (plan->d_descs) (void)hipFree(plan->d_descs);  // one block holds ids, results and flags too
+    if (plan->d_descs) {  // one block holds ids, results and flags too
+        pq_ctx *ctx = plan->ctx;
+        if (plan->block_bytes > ctx->spare_bytes) {  // kept for the next plan; the smaller one goes
+            if (ctx->spare_block) (void)hipFree(ctx->spare_block);
+            ctx->spare_block = plan->d_descs;
+            ctx->spare_bytes = plan->block_bytes;
+        } else {
+            (void)hipFree(plan->d_descs);
+        }
+    }
     delete plan;
 }
 
