@@ -253,3 +253,41 @@ def test_values_of_megabytes(ctx):
         assert c.result["status"] == K.OK and c.result["n_decoded"] == 130
         assert np.array_equal(c.ba_offsets[:131], offs) and np.array_equal(c.ba_data[:room], flat)
         assert guard_ok(c.guard) and guard_ok(c.area_guard)
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33, 34])
+def test_values_around_the_output_window(ctx, seed):
+    """Value lengths on either side of what a wave keeps of its output in LDS (2 KiB), long shared
+    prefixes across them: batches of every size from 1 to 64, values that go through memory, values
+    whose predecessor did, window wrap-around at every alignment of the output."""
+    rng = np.random.default_rng(seed)
+    vals, prev = [], b""
+    for i in range(700):
+        pick = rng.integers(0, 10)
+        if pick < 5:
+            n = int(rng.integers(0, 40))
+        elif pick < 7:
+            n = int(rng.integers(900, 1100))
+        elif pick < 9:
+            n = int(rng.integers(2030, 2070))
+        else:
+            n = int(rng.integers(3000, 5000))
+        keep = int(rng.integers(0, min(len(prev), n) + 1)) if rng.integers(0, 4) else 0
+        if rng.integers(0, 8) == 0:
+            keep = min(len(prev), n)                  # the whole value in front, or the whole of this one
+        prev = prev[:keep] + bytes(rng.integers(0, 256, size=n - keep, dtype=np.uint8))
+        vals.append(prev)
+    room = total_len(vals)
+    flat = np.frombuffer(b"".join(vals), dtype=np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(v) for v in vals])]).astype(np.uint32)
+    fs, ls = synth.delta_ba_encode(vals), synth.delta_length_ba_encode(vals)
+    cases = [_case(K.KIND_DELTA_BA, fs, 700, data_cap=room + k) for k in range(0, 48, 3)]
+    cases += [_case(K.KIND_DELTA_BA, fs, n, data_cap=room) for n in (1, 5, 64, 65, 333, 699)]
+    cases.append(_case(K.KIND_DELTA_LENGTH_BA, ls, 700))
+    run_cases(ctx, cases, seed=seed)
+    for c in cases:
+        _check(c)
+        nd = min(c.n, 700)
+        assert c.result["status"] == K.OK and c.result["n_decoded"] == nd
+        assert np.array_equal(c.ba_offsets[: nd + 1], offs[: nd + 1])
+        assert np.array_equal(c.ba_data[: int(offs[nd])], flat[: int(offs[nd])])
