@@ -148,6 +148,49 @@ __device__ __forceinline__ ByteArrayResult delta_length_ba_wave(uint32_t *window
                                                                 int lane)
 {
     ByteArrayResult res{PQ_OK, 0, 0, 0};
+    {
+        // The usual page in one pass: the lengths leave the delta decoder as offsets (a second
+        // scan inside the tile), the first value the bytes run out at is looked up afterwards.
+        // Anything else — a failing stream, a negative or huge length, sums that might not fit
+        // 32 bits — is decoded again below, lengths first.
+        WaveOffsets wo{0u, 0u};
+        const WaveDeltaResult fr = delta_wave<uint32_t, false, true>(window, S, len, 0x7fffffffu, area, lane, cap, &wo);
+        const bool usual = !fr.init_failed && (fr.status == PQ_OK || fr.status == PQ_EOF) && fr.n_decoded == fr.total &&
+                           uni(wo.big) == 0u;
+        if (usual) {
+            const uint32_t total = fr.total, m = min(n, total);
+            const uint64_t avail = (uint64_t)len - fr.consumed;  // bytes behind the lengths
+            if (lane == 0) area[total] = wo.sum;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            auto off = [&](uint32_t i) -> uint32_t {
+                return uni(__hip_atomic_load(area + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            };
+            uint32_t done = m;
+            uint64_t bytes = off(m);
+            res.status = n > total ? PQ_EOF : PQ_OK;  // next() past the last length (:205-207)
+            if (bytes > avail) {
+                // io.ReadFull of value `lo` fails (:212): the first i with off[i + 1] > avail
+                uint32_t lo = 0, hi = m - 1u;
+                while (lo < hi) {
+                    const uint32_t mid = lo + (hi - lo) / 2u;
+                    if ((uint64_t)off(mid + 1u) > avail)
+                        hi = mid;
+                    else
+                        lo = mid + 1u;
+                }
+                done = lo;
+                bytes = off(lo);
+                res.status = bytes == avail ? PQ_EOF : PQ_UNEXPECTED_EOF;
+                res.consumed = fr.consumed + avail;  // a short read takes what is left
+            } else {
+                res.consumed = fr.consumed + bytes;
+            }
+            wave_copy_bytes(data, S + fr.consumed, bytes, lane);
+            res.n_decoded = done;
+            return res;
+        }
+    }
     const ByteArrayLens lr = ba_lengths_wave(window, S, len, cap, area, lane);
     if (!lr.ok) {
         res.status = lr.status == kOverCap ? PQ_ERR_OUT_OF_RANGE : lr.status;

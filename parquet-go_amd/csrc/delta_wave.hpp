@@ -342,10 +342,21 @@ __device__ __forceinline__ int32_t wave_expand_min_delta(uint32_t hdr_lo, uint32
     return (int32_t)(x >> 1) ^ -(int32_t)(x & 1u);
 }
 
+// OFFS (uint32 values only): what goes to dst is not value i but the sum of the values in front of
+// it — the values are the lengths of a DELTA_LENGTH_BYTE_ARRAY page and dst its offsets.  `sum` is
+// the running total; `big` says that a value of 2^24 or more (a negative one included) or a total
+// of 2^31 or more was seen, i.e. that the 32-bit sums may have wrapped and the caller has to take
+// the lengths one by one.
+struct WaveOffsets {
+    uint32_t sum;
+    uint32_t big;
+};
+
 // CLIPPED = false: a whole block, stored unconditionally.
-template <typename UT, bool CLIPPED, uint32_t LG>
+template <typename UT, bool CLIPPED, uint32_t LG, bool OFFS = false>
 __device__ __forceinline__ void wave_decode_tile(const uint32_t *lds, const WaveTile &t, UT &carry, UT *dst,
-                                                 uint32_t clip, bool vec_ok, int lane, WaveLane ln)
+                                                 uint32_t clip, bool vec_ok, int lane, WaveLane ln,
+                                                 WaveOffsets *wo = nullptr)
 {
     const uint32_t w = __builtin_amdgcn_ubfe(t.widths, ln.sh8, 8u);
     const uint32_t pre = __builtin_amdgcn_ubfe(t.prefix, ln.sh8, 8u);
@@ -396,6 +407,16 @@ __device__ __forceinline__ void wave_decode_tile(const uint32_t *lds, const Wave
         v0 = carry + (incl - pair);
         v1 = v0 + a;
         carry += wave_last_u32(incl);
+        if constexpr (OFFS) {
+            const uint32_t l0 = (!CLIPPED || p < clip) ? v0 : 0u, l1 = (!CLIPPED || p + 1u < clip) ? v1 : 0u;
+            const uint32_t both = l0 + l1;
+            const uint32_t oincl = wave_scan_u32(both);
+            wo->big |= __builtin_amdgcn_ballot_w64((l0 | l1) >= (1u << 24)) != 0ull ? 1u : 0u;
+            v0 = wo->sum + (oincl - both);
+            v1 = v0 + l0;
+            wo->sum += wave_last_u32(oincl);
+            wo->big |= wo->sum >> 31;
+        }
         if ((!CLIPPED || p + 1u < clip) && vec_ok) {
             store_nt8(dst + p, v0, v1);
             return;
@@ -415,10 +436,11 @@ struct WaveDeltaResult {
 
 // The tiles of one page behind its stream header (pos = the first block header, first = the first
 // value, the window [c0, c0 + kDwChunk) staged).  LG = log2 of the values per miniblock.
-template <typename UT, uint32_t LG>
+template <typename UT, uint32_t LG, bool OFFS = false>
 __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const uint8_t *S, int64_t len, uint32_t n,
                                                             UT *dst, int lane, WavePrefetch &pf, int64_t c0, int64_t pos,
-                                                            uint32_t total32, uint64_t first, bool vec_ok)
+                                                            uint32_t total32, uint64_t first, bool vec_ok,
+                                                            WaveOffsets *wo = nullptr)
 {
     WaveDeltaResult res{PQ_OK, 0, 0, 0, total32};
     WaveState<UT> st;
@@ -473,7 +495,7 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
         while (!st.finished && (tail || o + (uint32_t)kDwBlockMax <= (uint32_t)kDwChunk)) {
             WaveTile t = wave_tile_none();
             if (wave_walk_fast<LG>(t, lds, o, lim, p0, st.need, blk)) {
-                wave_decode_tile<UT, false, LG>(lds, t, carry, dst, 0xffffffffu, vec_ok, lane, ln);
+                wave_decode_tile<UT, false, LG, OFFS>(lds, t, carry, dst, 0xffffffffu, vec_ok, lane, ln, wo);
                 continue;
             }
             st.pos = c0 + (int64_t)o;
@@ -495,7 +517,7 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
             t.p0 = uni(t.p0);
             t.min_delta = ((uint64_t)uni((uint32_t)(t.min_delta >> 32)) << 32) | uni((uint32_t)t.min_delta);
             const uint32_t clip = st.finished ? st.n_ok : 0xffffffffu;
-            if (t.valid) wave_decode_tile<UT, true, LG>(lds, t, carry, dst, clip, vec_ok, lane, ln);
+            if (t.valid) wave_decode_tile<UT, true, LG, OFFS>(lds, t, carry, dst, clip, vec_ok, lane, ln, wo);
         }
         if (st.finished) break;
         wave_sync();
@@ -516,10 +538,12 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
 // Decode one page with one wave.  `lds` is this wave's private window.  A stream that
 // declares more than `cap` values is not decoded at all (status kOverCap).  WIDE = false: only
 // the 128 / 4 layout is taken (for callers whose streams never use the other one).
-template <typename UT, bool WIDE = true>
+template <typename UT, bool WIDE = true, bool OFFS = false>
 __device__ __forceinline__ WaveDeltaResult delta_wave(uint32_t *lds, const uint8_t *S, int64_t len, uint32_t n,
-                                                      UT *dst, int lane, uint32_t cap = 0xffffffffu)
+                                                      UT *dst, int lane, uint32_t cap = 0xffffffffu,
+                                                      WaveOffsets *wo = nullptr)
 {
+    static_assert(!OFFS || (sizeof(UT) == 4 && !WIDE), "offsets come from 32-bit lengths in the 128 / 4 layout");
     const uint8_t *B = reinterpret_cast<const uint8_t *>(lds);
     const bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & (2 * sizeof(UT) - 1)) == 0;
     WaveDeltaResult res{PQ_OK, 0, 0, 0, 0};
@@ -587,7 +611,7 @@ __device__ __forceinline__ WaveDeltaResult delta_wave(uint32_t *lds, const uint8
     if constexpr (WIDE) {
         if (bs32 == 256u) return delta_wave_tiles<UT, 6>(lds, S, len, n, dst, lane, pf, c0, pos, total32, first, vec_ok);
     }
-    return delta_wave_tiles<UT, 5>(lds, S, len, n, dst, lane, pf, c0, pos, total32, first, vec_ok);
+    return delta_wave_tiles<UT, 5, OFFS>(lds, S, len, n, dst, lane, pf, c0, pos, total32, first, vec_ok, wo);
 }
 
 } // namespace pq
