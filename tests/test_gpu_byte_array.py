@@ -291,3 +291,38 @@ def test_values_around_the_output_window(ctx, seed):
         assert c.result["status"] == K.OK and c.result["n_decoded"] == nd
         assert np.array_equal(c.ba_offsets[: nd + 1], offs[: nd + 1])
         assert np.array_equal(c.ba_data[: int(offs[nd])], flat[: int(offs[nd])])
+
+
+def test_lengths_at_the_limits_of_the_one_pass_path(ctx):
+    """DELTA_LENGTH_BYTE_ARRAY lists whose entries sit at 2^24 and whose totals pass 2^31 (the body is
+    short, so DecodeValues runs out of bytes somewhere): the decoder has to notice that its 32-bit
+    running sums are no longer safe and still stop at the value the reference stops at."""
+    rng = np.random.default_rng(41)
+    cases = []
+    for it in range(120):
+        n = int(rng.integers(2, 500))
+        if n % 128 == 1:
+            n += 1
+        sl = rng.integers(0, 30, size=n).astype(np.int64)
+        kind = it % 6
+        where = int(rng.integers(0, n))
+        if kind == 0:
+            sl[where] = (1 << 24) - 1                  # the largest length the one pass takes
+        elif kind == 1:
+            sl[where] = 1 << 24
+        elif kind == 2:
+            sl[rng.integers(0, n, size=3)] = (1 << 31) - 1 - int(rng.integers(0, 3))   # totals beyond 2^32
+        elif kind == 3:
+            sl[:] = rng.integers((1 << 23) - 40, 1 << 23, size=n)      # each fine, the total passes 2^31
+        elif kind == 4:
+            sl[where] = -1
+            sl[(where + 7) % n] = 1 << 30
+        body_len = int(rng.choice([0, 1, 29, 300, int(np.clip(sl, 0, None)[: n // 2].sum() % 5000)]))
+        body = rng.integers(0, 256, size=body_len, dtype=np.uint8)
+        for pull in (n, int(rng.integers(0, n + 2))):
+            cases.append(_case(K.KIND_DELTA_LENGTH_BA, dlba_stream(sl, body), pull))
+    run_cases(ctx, cases, seed=12)
+    for c in cases:
+        _check(c)
+    seen = {int(c.result["status"]) for c in cases}
+    assert {K.EOF, K.UNEXPECTED_EOF, K.BYTE_ARRAY_NEGATIVE_LEN} <= seen
