@@ -379,9 +379,16 @@ def main():
     if want("c4"):
         bench_nested(ctx, stream, args.pages, 20000)
     if want("c2x"):
-        for w in (4, 8, 24, 30):
+        for w in (4, 8, 24, 30, 32):
             bench_delta(ctx, stream, args.pages, 20000, 64, w)
         bench_delta(ctx, stream, args.pages, 20000, 32, 12)
+    if want("c2big"):    # the large-page variant: one wave per page leaves most of the machine idle
+        bench_delta(ctx, stream, 100, 1_000_000, 64, 16)
+        bench_delta(ctx, stream, 1000, 100_000, 64, 16)
+        ctx.set_option(capi.OPT_DELTA_WAVE_MIN_PAGES, 1 << 30)    # the workgroup-per-page kernel instead
+        bench_delta(ctx, stream, 100, 1_000_000, 64, 16)
+        bench_delta(ctx, stream, 1000, 100_000, 64, 16)
+        ctx.set_option(capi.OPT_DELTA_WAVE_MIN_PAGES, 1)
     if want("plain"):
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_PLAIN, 8, "P PLAIN int64")
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_PLAIN, 4, "P PLAIN int32")
