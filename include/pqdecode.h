@@ -211,7 +211,11 @@ typedef struct pq_page_result {
  * on the context's stream, and touches no host memory: this is the path the
  * reference's readPageData loop (file-reader.go:268-302) maps to when all pages
  * of a column chunk are handed over at once.  Buffers are device pointers;
- * *_bytes are their sizes (used only for range checks). */
+ * *_bytes are their sizes (used only for range checks).
+ * pq_plan_create copies descs (the caller's array is free again on return) and
+ * waits for the context's stream.  A plan belongs to its context: destroy it
+ * before the context.  The context keeps the device block of the largest plan
+ * destroyed so far for the next plan to use, and frees it in pq_ctx_destroy. */
 typedef struct pq_plan pq_plan;
 
 int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_plan **out);

@@ -4,7 +4,7 @@
 tag=$1; pages=${2:-8000}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/profcfg_$tag; mkdir -p $out
-timeout -k 10 300 python3 tools/bench_configs.py --pages $pages > $out/configs.jsonl 2> $out/configs.err || { tail -3 $out/configs.err; exit 1; }
+timeout -k 10 600 python3 tools/bench_configs.py --pages $pages > $out/configs.jsonl 2> $out/configs.err || { tail -3 $out/configs.err; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 tools/bench_configs.py --only c1,c1b,c4,plain,bytes,walk,levels --pages $pages > $out/under_rocprof.jsonl 2> $out/trace_err.log || exit 1
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 tools/pmc_pass.sh $out/fetch "FETCH_SIZE" python3 tools/bench_configs.py --only c1,c1b,c4 --pages $pages || exit 1
