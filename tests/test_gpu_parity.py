@@ -663,3 +663,55 @@ def test_single_call_entry_points(ctx):
     v32 = np.cumsum(rng.integers(-100, 1 << 12, size=5000)).astype(np.int32)
     r = ctx.delta_decode(synth.delta_encode(v32, 32), 5000, 32)
     assert r["status"] == K.OK and np.array_equal(r["values"], v32)
+
+
+def test_plans_side_by_side_and_one_after_another(ctx):
+    """Plans of one context: two alive at once, their runs interleaved; a destroyed plan's device
+    block taken over by a smaller plan, outgrown by a larger one."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    dev = torch.device("cuda:0")
+
+    def make(pages, n):
+        vals = [np.cumsum(rng.integers(-50, 1000, size=n)).astype(np.int64) + p for p in range(pages)]
+        streams = [synth.delta_encode(v, 64) for v in vals]
+        offs = np.concatenate([[0], np.cumsum([s.size for s in streams])])
+        descs = np.zeros(pages, dtype=capi.DESC_DTYPE)
+        descs["kind"] = capi.KIND_DELTA64
+        descs["src_off"], descs["src_len"], descs["n_values"] = offs[:-1], [s.size for s in streams], n
+        descs["dst_off"] = np.arange(pages, dtype=np.uint64) * np.uint64(8 * n)
+        src = torch.from_numpy(np.concatenate(streams + [np.zeros(16, np.uint8)])).to(dev)
+        out = torch.zeros(pages * n * 8, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()                 # the plans run on the context's own stream
+        return descs, src, out, np.concatenate(vals)
+
+    def check(plan, src, out, want, pages):
+        res = plan.results()
+        assert res.size == pages and (res["status"] == capi.OK).all()
+        assert np.array_equal(out.cpu().numpy().view(np.int64), want)
+
+    a, b = make(300, 258), make(7, 1000)
+    pa, pb = ctx.plan(a[0]), ctx.plan(b[0])
+    for _ in range(2):
+        pa.run(a[1].data_ptr(), a[1].numel(), a[2].data_ptr(), a[2].numel())
+        pb.run(b[1].data_ptr(), b[1].numel(), b[2].data_ptr(), b[2].numel())
+    check(pa, a[1], a[2], a[3], 300)
+    check(pb, b[1], b[2], b[3], 7)
+    pa.close()                                  # the context keeps this block ...
+    c = make(40, 130)
+    pc = ctx.plan(c[0])                         # ... a smaller plan takes it ...
+    pc.run(c[1].data_ptr(), c[1].numel(), c[2].data_ptr(), c[2].numel())
+    check(pc, c[1], c[2], c[3], 40)
+    d = make(900, 64)
+    pd = ctx.plan(d[0])                         # ... a larger one gets a block of its own
+    pd.run(d[1].data_ptr(), d[1].numel(), d[2].data_ptr(), d[2].numel())
+    pb.run(b[1].data_ptr(), b[1].numel(), b[2].data_ptr(), b[2].numel())
+    check(pd, d[1], d[2], d[3], 900)
+    check(pb, b[1], b[2], b[3], 7)
+    for p in (pb, pc, pd):
+        p.close()
+    e = ctx.plan(a[0])
+    e.run(a[1].data_ptr(), a[1].numel(), a[2].data_ptr(), a[2].numel())
+    check(e, a[1], a[2], a[3], 300)
+    e.close()
