@@ -213,7 +213,8 @@ typedef struct pq_page_result {
  * of a column chunk are handed over at once.  Buffers are device pointers;
  * *_bytes are their sizes (used only for range checks).
  * pq_plan_create copies descs (the caller's array is free again on return) and
- * waits for the context's stream.  A plan belongs to its context: destroy it
+ * sends the tables on the context's stream without waiting for them; it waits
+ * only when the plan before last is still being sent.  A plan belongs to its context: destroy it
  * before the context.  The context keeps the device block of the largest plan
  * destroyed so far for the next plan to use, and frees it in pq_ctx_destroy. */
 typedef struct pq_plan pq_plan;

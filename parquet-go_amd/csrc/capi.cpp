@@ -32,8 +32,11 @@ struct pq_ctx {
     // enough) and a pinned host image the plan tables are put together in
     void *spare_block = nullptr;
     size_t spare_bytes = 0;
-    void *host_img = nullptr;
-    size_t host_img_cap = 0;
+    // two images, used in turn: a plan's copy may still be in flight when the next plan is made
+    void *host_img[2] = {nullptr, nullptr};
+    size_t host_img_cap[2] = {0, 0};
+    hipEvent_t host_img_done[2] = {nullptr, nullptr};  // recorded behind the copy out of the image
+    unsigned host_img_next = 0;
 };
 
 struct pq_plan {
@@ -246,7 +249,10 @@ void pq_ctx_destroy(pq_ctx *ctx)
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
     if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->spare_block) (void)hipFree(ctx->spare_block);
-    if (ctx->host_img) (void)hipHostFree(ctx->host_img);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->host_img[i]) (void)hipHostFree(ctx->host_img[i]);
+        if (ctx->host_img_done[i]) (void)hipEventDestroy(ctx->host_img_done[i]);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -445,30 +451,35 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
             e = hipMalloc((void **)&block, total);
             plan->block_bytes = total;
         }
-        if (e == hipSuccess && ctx->host_img_cap < img) {
-            if (ctx->host_img) (void)hipHostFree(ctx->host_img);
-            ctx->host_img = nullptr;
-            ctx->host_img_cap = 0;
+        const unsigned slot = ctx->host_img_next++ & 1u;
+        if (e == hipSuccess && !ctx->host_img_done[slot])
+            e = hipEventCreateWithFlags(&ctx->host_img_done[slot], hipEventDisableTiming);
+        // the copy of the plan before last came out of this image: it has to be over
+        if (e == hipSuccess) e = hipEventSynchronize(ctx->host_img_done[slot]);
+        if (e == hipSuccess && ctx->host_img_cap[slot] < img) {
+            if (ctx->host_img[slot]) (void)hipHostFree(ctx->host_img[slot]);
+            ctx->host_img[slot] = nullptr;
+            ctx->host_img_cap[slot] = 0;
             const size_t cap = img + img / 2;
-            e = hipHostMalloc(&ctx->host_img, cap, hipHostMallocDefault);
-            if (e == hipSuccess) ctx->host_img_cap = cap;
+            e = hipHostMalloc(&ctx->host_img[slot], cap, hipHostMallocDefault);
+            if (e == hipSuccess) ctx->host_img_cap[slot] = cap;
         }
         if (e == hipSuccess) {
             plan->d_descs = reinterpret_cast<pq_page_desc *>(block);
             plan->d_ids = reinterpret_cast<uint32_t *>(block + db);
             plan->d_flags = reinterpret_cast<uint32_t *>(block + db + ib);
             plan->d_results = reinterpret_cast<pq_page_result *>(block + img);
-            uint8_t *h = static_cast<uint8_t *>(ctx->host_img);
+            uint8_t *h = static_cast<uint8_t *>(ctx->host_img[slot]);
             std::memcpy(h, descs, n_pages * sizeof(pq_page_desc));
             std::memcpy(h + db, all.data(), n_pages * sizeof(uint32_t));
             std::memset(h + db + n_pages * sizeof(uint32_t), 0, ib - n_pages * sizeof(uint32_t) + kFlagBytes);
             e = hipMemcpyAsync(block, h, img, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipEventRecord(ctx->host_img_done[slot], ctx->stream);
         } else if (block) {
             plan->d_descs = reinterpret_cast<pq_page_desc *>(block);  // for pq_plan_destroy
         }
+        // nothing waits here: the tables are on their way on the stream the plan runs on
         if (e == hipSuccess) e = hipMemsetAsync(plan->d_results, 0xff, rb, ctx->stream);
-        // the image is the context's: the next plan may not overwrite it under a copy in flight
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
             hip_ok(ctx, e, "pq_plan_create");
             pq_plan_destroy(plan);
