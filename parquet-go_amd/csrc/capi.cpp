@@ -926,9 +926,10 @@ int pq_chunk_page_descs(const pq_chunk_desc *chunk, const pq_page_info *infos, u
         if (d.value_kind == PQ_KIND_DELTA_LENGTH_BA || d.value_kind == PQ_KIND_DELTA_BA) {
             const bool front = d.value_kind == PQ_KIND_DELTA_BA;
             const uint64_t room = front ? layout->delta_ba_room : d.src_len;
-            d.dst_off = layout->values_off;
+            // 16-byte boundaries: the value bytes go out in 16-byte pieces, the offsets two a store
+            d.dst_off = (layout->values_off + 15) / 16 * 16;
             d.dst_cap = front ? layout->delta_ba_room : 0;
-            d.dict_off = (d.dst_off + room + 3) / 4 * 4;
+            d.dict_off = (d.dst_off + room + 15) / 16 * 16;
             d.dict_len = d.n_values;
             layout->values_off = d.dict_off + 4 * ((front ? 2ull : 1ull) * d.n_values + 1);
         } else {
