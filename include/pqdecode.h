@@ -146,8 +146,9 @@ int pq_bitunpack64(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, size_
 #define PQ_KIND_DELTA_LENGTH_BA 11 /* ByteArrayDeltaLengthDecoder.Init + DecodeValues(dest[:n_values])
                               (types/byte-array.go:168-219).  Output, both in the values buffer:
                               the value bytes back to back at dst_off (at most src_len of them),
-                              and at dict_off (4-byte aligned) n_decoded + 1 uint32 offsets into
-                              them, offsets[0] = 0.  dict_len = the number of lengths the area at
+                              and at dict_off (4-byte aligned; 16-byte boundaries for both areas
+                              are faster, and what pq_chunk_page_descs lays out) n_decoded + 1
+                              uint32 offsets into them, offsets[0] = 0.  dict_len = the number of lengths the area at
                               dict_off has room for (it holds dict_len + 1 words and serves as
                               scratch): at least n_values, and at least the count the stream
                               itself declares, else the page ends with PQ_ERR_OUT_OF_RANGE.
