@@ -6,7 +6,12 @@ block size 128 / 4 miniblocks, delta - minDelta uniform in [0, 2^16), pages writ
 the reference encoder's algorithm (parquet_go_amd.synth.delta_encode).  A "step" is
 one pass of the decode kernels over all pages, inputs already resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched under torchrun)
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no RANK in the environment the process starts N ranks of itself (one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before anything touches the GPU and waits for
+them; launched under torchrun it is one of the ranks.  `--dry-run` forms the ranks over gloo,
+partitions the pages and prints the partition without decoding anything (no GPU needed).
 
 Rank 0 prints ONE JSON line: whole-job output GB/s, the roofline object of the
 dominant kernel (algorithmic in+out bytes / HIP-event time, against 8 TB/s HBM) and
@@ -26,6 +31,40 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(script, argv, n):
+    """Start n ranks of `script` (one process per GPU) and wait for them.  The caller must not have
+    touched the GPU: the children are fresh interpreters, nothing is exec'ed over this process.
+    Returns the largest exit status."""
+    import subprocess
+
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", script] + list(argv), env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def rank_pages(total_pages, rank, world):
+    """Global page indices [lo, hi) of one rank: the job's pages as one chunk cut by
+    parquet_go_amd.shard.plan_shards (contiguous page ranges, nothing shared)."""
+    from parquet_go_amd import shard
+
+    pieces = shard.plan_shards([shard.ChunkInfo(total_pages, 0, 0)], world)[rank]
+    return (pieces[0].page_lo, pieces[0].page_hi) if pieces else (0, 0)
 
 
 def make_pages(n_pages, values_per_page, width, seed):
@@ -123,17 +162,45 @@ def main():
     ap.add_argument("--width", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="form the ranks (gloo), print every rank's page range, decode nothing")
     args = ap.parse_args()
 
-    import torch
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under a launcher: be the launcher.  Nothing here has imported torch or touched HIP.
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1) and rank == 0:
+        print("bench.py: --gpus %d but the launcher formed WORLD_SIZE=%d ranks; using the latter"
+              % (args.gpus, world), file=sys.stderr)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # pages are independent: the job's world x pages pages are cut into one range per rank
+    page_lo, page_hi = rank_pages(world * args.pages, rank, world)
+
+    if args.dry_run:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        mine = {"rank": rank, "world": world, "page_lo": page_lo, "page_hi": page_hi}
+        ranges = [mine]
+        if world > 1:
+            ranges = [None] * world
+            dist.all_gather_object(ranges, mine)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "total_pages": world * args.pages,
+                              "ranks": ranges}), flush=True)
+        return
+
+    import torch
+
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
@@ -142,7 +209,7 @@ def main():
     from parquet_go_amd import capi
 
     n = args.values_per_page
-    # pages are independent: each rank owns its own pages, nothing is exchanged
+    assert page_hi - page_lo == args.pages
     src, offs, lens, expected = make_pages(args.pages, n, args.width, seed=0xC2 + 7919 * rank)
     descs = np.zeros(args.pages, dtype=capi.DESC_DTYPE)
     descs["kind"] = capi.KIND_DELTA64
@@ -235,6 +302,7 @@ def main():
                 "encoded_bytes_per_gpu": in_bytes,
                 "decoded_bytes_per_gpu": out_bytes,
                 "parallelism": "pages partitioned over %d GPU(s), no collective" % world,
+                "world_size": world,
             },
             "roofline": {
                 "bound": "hbm",

@@ -149,3 +149,23 @@ def test_two_ranks_cover_the_file_once(n_chunks_used):
 
 if HERE not in sys.path:
     sys.path.insert(0, HERE)
+
+
+def test_bench_forms_its_own_ranks_with_disjoint_pages():
+    """`bench.py --gpus 2 --dry-run` starts two ranks by itself (no launcher), which agree over gloo
+    on a partition of the job's pages: disjoint ranges that cover everything."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--dry-run",
+                          "--pages", "37"], env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                      # rank 0 prints the one line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["total_pages"] == 74
+    ranks = sorted(rec["ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["world"] == 2 for r in ranks)
+    assert ranks[0]["page_lo"] == 0 and ranks[0]["page_hi"] == ranks[1]["page_lo"] and ranks[1]["page_hi"] == 74
+    assert all(r["page_hi"] > r["page_lo"] for r in ranks)

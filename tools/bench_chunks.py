@@ -11,8 +11,7 @@ of one slot overlap the decode of another.  Host buffers are pinned.
 Reports, per job (all ranks): the end-to-end rate (output GB/s including both copies) and the
 device-resident rate of the same decode launches with the data already in HBM.
 
-    python tools/bench_chunks.py                 (1 GPU)
-    torchrun --nproc-per-node N tools/bench_chunks.py --gpus N
+    python tools/bench_chunks.py [--gpus N]      (N > 1: starts its own N ranks, or runs under torchrun)
 
 Page payloads repeat: a chunk is built from a pool of `--distinct` distinct pages (encoding 51 200
 distinct pages on the host takes longer than everything measured here); offsets, sizes and the
@@ -28,9 +27,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch  # noqa: E402
-
-from parquet_go_amd import capi, shard, synth  # noqa: E402
 
 
 def build_pool(kind, distinct, n, seed):
@@ -72,6 +68,15 @@ def main():
     ap.add_argument("--repeats", type=int, default=3)
     ap.add_argument("--wave-min-pages", type=int, default=-1, help="override both kernel-selection thresholds")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # be the launcher: N fresh ranks of this script, started before anything here touches the GPU
+        from bench import spawn_ranks
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
+    global torch, capi, shard, synth
+    import torch
+    from parquet_go_amd import capi, shard, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
