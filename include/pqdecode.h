@@ -406,6 +406,17 @@ int pq_levels_pack(pq_ctx *ctx, const int32_t *levels, uint64_t n, int bit_width
 int pq_column_entries_dev(pq_ctx *ctx, const int32_t *d_def, const int32_t *d_rep, uint64_t n,
                           uint32_t max_def, uint32_t max_rep, int repeated, uint32_t *d_offsets,
                           void *d_validity, int32_t *d_entry_def, pq_entries_result *d_result);
+/* pq_column_entries_dev for callers that cannot allocate (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
+ * arguments, same outputs; the workspace is a static device array inside the library (8 MiB on
+ * every GPU the library runs on, held until the process ends), so the call allocates nothing and
+ * frees nothing.  n <= PQ_NOALLOC_MAX_SLOTS, else PQ_ERR_OUT_OF_RANGE.  All calls on one GPU share
+ * that array, whatever their context: calls that overlap on one GPU race; run them in stream
+ * order or one after the other. */
+#define PQ_NOALLOC_MAX_SLOTS 30000000ull
+int pq_column_entries_noalloc(pq_ctx *ctx, const int32_t *d_def, const int32_t *d_rep, uint64_t n,
+                              uint32_t max_def, uint32_t max_rep, int repeated, uint32_t *d_offsets,
+                              void *d_validity, int32_t *d_entry_def, pq_entries_result *d_result);
 int pq_column_entries(pq_ctx *ctx, const int32_t *def, const int32_t *rep, uint64_t n, uint32_t max_def,
                       uint32_t max_rep, int repeated, uint32_t *offsets, uint8_t *validity,
                       int32_t *entry_def, pq_entries_result *result);

@@ -35,7 +35,7 @@ EXPORTS = [
     "pq_plan_create", "pq_plan_run", "pq_plan_results", "pq_plan_destroy", "pq_decode_pages",
     "pq_hybrid_decode", "pq_dict_decode", "pq_levels_decode", "pq_delta_decode32",
     "pq_delta_decode64", "pq_plain_decode", "pq_bool_plain_decode",
-    "pq_levels_pack_dev", "pq_levels_pack", "pq_column_entries_dev", "pq_column_entries",
+    "pq_levels_pack_dev", "pq_levels_pack", "pq_column_entries_dev", "pq_column_entries", "pq_column_entries_noalloc",
     "pq_delta_length_ba_decode", "pq_delta_ba_decode",
     "pq_walk_chunks_dev", "pq_walk_chunks", "pq_chunk_page_descs", "pq_chunks_page_descs",
 ]
@@ -146,7 +146,7 @@ def load():
                                         C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         for name in ("pq_levels_pack_dev", "pq_levels_pack"):
             getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
-        for name in ("pq_column_entries_dev", "pq_column_entries"):
+        for name in ("pq_column_entries_dev", "pq_column_entries", "pq_column_entries_noalloc"):
             getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pq_delta_length_ba_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p,
@@ -359,10 +359,12 @@ class Context:
                     validity=validity[:(n + 31) // 32 * 4].copy(), entry_def=entry_def[:ne].copy())
 
     def column_entries_dev(self, d_def, d_rep, n, max_def, max_rep, repeated, d_offsets, d_validity, d_entry_def,
-                           d_result):
-        st = self._lib.pq_column_entries_dev(self._h, C.c_void_p(d_def), C.c_void_p(d_rep), int(n), int(max_def),
-                                             int(max_rep), int(bool(repeated)), C.c_void_p(d_offsets),
-                                             C.c_void_p(d_validity), C.c_void_p(d_entry_def), C.c_void_p(d_result))
+                           d_result, noalloc=False):
+        """noalloc: through pq_column_entries_noalloc (the library's static device workspace)."""
+        fn = self._lib.pq_column_entries_noalloc if noalloc else self._lib.pq_column_entries_dev
+        st = fn(self._h, C.c_void_p(d_def), C.c_void_p(d_rep), int(n), int(max_def),
+                int(max_rep), int(bool(repeated)), C.c_void_p(d_offsets),
+                C.c_void_p(d_validity), C.c_void_p(d_entry_def), C.c_void_p(d_result))
         if st != OK:
             raise PqError(st, self._lib.pq_last_error(self._h).decode())
 

@@ -562,4 +562,47 @@ hipError_t launch_column_entries(hipStream_t s, const int32_t *d_def, const int3
     return hipGetLastError();
 }
 
+// ---- column entries without any allocation ---------------------------------------------------
+// The same three launches over a workspace that is part of the library's device image: a
+// file-scope device array, one copy per GPU, held until the process ends.  In host code the
+// array's name is only a stand-in for the symbol; the device address comes from
+// hipGetSymbolAddress, asked once per device (static_scratch_init, called when a context is
+// created on the device) and kept in g_scratch[device].
+constexpr size_t kStaticScratchBytes = 8u << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static void *g_scratch[kMaxDevices];          // device address of `scratch` on each GPU (null: not asked yet)
+static hipError_t g_scratch_err[kMaxDevices];  // why it is null after asking
+
+size_t static_scratch_bytes() { return kStaticScratchBytes; }
+
+// Once per device, with that device current.  Not thread-safe against itself for one device: the
+// caller (pq_ctx_create) serialises.
+hipError_t static_scratch_init(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (g_scratch[device]) return hipSuccess;
+    void *ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    g_scratch_err[device] = e;
+    if (e != hipSuccess) return e;
+    g_scratch[device] = ptr;
+    return hipSuccess;
+}
+
+hipError_t launch_column_entries_static(int device, hipStream_t s, const int32_t *d_def, const int32_t *d_rep,
+                                        uint64_t n, int32_t max_def, int32_t max_rep, int repeated,
+                                        uint32_t *d_offsets, uint32_t *d_validity, int32_t *d_entry_def,
+                                        pq_entries_result *d_result)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    void *ptr = g_scratch[device];
+    if (!ptr) return g_scratch_err[device] != hipSuccess ? g_scratch_err[device] : hipErrorNotInitialized;
+    if (entries_workspace_bytes(n) > kStaticScratchBytes) return hipErrorInvalidValue;
+    // every word of the workspace a launch reads it has written before: nothing to clear
+    return launch_column_entries(s, d_def, d_rep, n, max_def, max_rep, repeated, d_offsets, d_validity, d_entry_def,
+                                 d_result, ptr);
+}
+
 }  // namespace pq

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -235,6 +236,13 @@ int pq_ctx_create(int device, void *hip_stream, pq_ctx **out)
             return PQ_ERR_HIP;
         }
         ctx->own_stream = true;
+    }
+    {
+        // the static device workspace of the allocation-free entry point: its address on this
+        // device is asked for here, once, so that the entry point itself only launches
+        static std::mutex m;
+        std::lock_guard<std::mutex> lock(m);
+        hip_ok(ctx, pq::static_scratch_init(device), "hipGetSymbolAddress(scratch)");  // failure surfaces at the entry point
     }
     *out = ctx;
     return PQ_OK;
@@ -1048,6 +1056,25 @@ int pq_column_entries_dev(pq_ctx *ctx, const int32_t *d_def, const int32_t *d_re
     PQ_HIP(ctx, pq::launch_column_entries(ctx->stream, d_def, d_rep, n, (int32_t)max_def, (int32_t)max_rep,
                                           repeated, d_offsets, static_cast<uint32_t *>(d_validity), d_entry_def,
                                           d_result, ctx->work));
+    return PQ_OK;
+}
+
+int pq_column_entries_noalloc(pq_ctx *ctx, const int32_t *d_def, const int32_t *d_rep, uint64_t n,
+                              uint32_t max_def, uint32_t max_rep, int repeated, uint32_t *d_offsets,
+                              void *d_validity, int32_t *d_entry_def, pq_entries_result *d_result)
+{
+    if (!ctx || !d_offsets || !d_result || n > 0x7fffffffull) return PQ_ERR_BAD_ARGUMENT;
+    if (max_def > 0xffffu || max_rep > 0xffffu) return PQ_ERR_BAD_ARGUMENT;
+    if (n && (!d_def || !d_validity || !d_entry_def || (repeated && !d_rep))) return PQ_ERR_BAD_ARGUMENT;
+    if (reinterpret_cast<uintptr_t>(d_validity) & 3u) return PQ_ERR_BAD_ARGUMENT;
+    if (n > PQ_NOALLOC_MAX_SLOTS || pq::entries_workspace_bytes(n) > pq::static_scratch_bytes()) {
+        ctx->last_error = "pq_column_entries_noalloc: more level slots than the static workspace serves";
+        return PQ_ERR_OUT_OF_RANGE;
+    }
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    PQ_HIP(ctx, pq::launch_column_entries_static(ctx->device, ctx->stream, d_def, d_rep, n, (int32_t)max_def,
+                                                 (int32_t)max_rep, repeated, d_offsets,
+                                                 static_cast<uint32_t *>(d_validity), d_entry_def, d_result));
     return PQ_OK;
 }
 

@@ -63,6 +63,15 @@ hipError_t launch_column_entries(hipStream_t s, const int32_t *d_def, const int3
                                  uint32_t *d_validity, int32_t *d_entry_def, pq_entries_result *d_result,
                                  void *d_work);
 
+// The same over the library's static device workspace (static_scratch_bytes() per GPU): no
+// allocation.  static_scratch_init(device) once per device, with that device current, first.
+size_t static_scratch_bytes();
+hipError_t static_scratch_init(int device);
+hipError_t launch_column_entries_static(int device, hipStream_t s, const int32_t *d_def, const int32_t *d_rep,
+                                        uint64_t n, int32_t max_def, int32_t max_rep, int repeated,
+                                        uint32_t *d_offsets, uint32_t *d_validity, int32_t *d_entry_def,
+                                        pq_entries_result *d_result);
+
 // Page-header walk (walk.hip): one wave per chunk; d_infos / d_results as in pq_walk_chunks_dev.
 hipError_t launch_walk_chunks(hipStream_t s, const pq_chunk_desc *d_chunks, uint32_t n_chunks, const void *d_src,
                               pq_page_info *d_infos, pq_chunk_result *d_results);
