@@ -95,6 +95,15 @@ int pq_ctx_synchronize(pq_ctx *ctx);
 /* PQ_OPT_HYBRID_WAVE_MIN_PAGES: the same choice for hybrid / dictionary / level streams and
  * whole data pages.  Default 1 (equal up to about 256 pages, the wave kernels ahead beyond). */
 #define PQ_OPT_HYBRID_WAVE_MIN_PAGES 2
+/* PQ_OPT_SEGMENT_MAX_PAGES: a plan with fewer than this many DELTA32 (or DELTA64) descriptors has
+ * its large ones decoded in segments, many waves to a page (a page is one serial chain of blocks,
+ * encoding/delta-binary-packed-decoder.go:130-147; a few large pages would otherwise leave most of
+ * the machine idle).  Default 2048; 0 = never.  Results are the same either way.
+ * PQ_OPT_SEGMENT_BYTES: bytes of the stream per segment, a multiple of 16 from 2048 on; 0 (the
+ * default) = chosen from the plan's size, 8 to 64 KiB.  Pages shorter than three segments are not
+ * cut.  Both options apply to plans created after the call. */
+#define PQ_OPT_SEGMENT_MAX_PAGES 3
+#define PQ_OPT_SEGMENT_BYTES 4
 int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value);
 const char *pq_status_string(int status);
 const char *pq_last_error(pq_ctx *ctx); /* text of the last HIP failure on ctx */
@@ -216,7 +225,9 @@ typedef struct pq_page_result {
  * pq_plan_create copies descs (the caller's array is free again on return) and
  * sends the tables on the context's stream without waiting for them; it waits
  * only when the plan before last is still being sent.  A plan belongs to its context: destroy it
- * before the context.  The context keeps the device block of the largest plan
+ * before the context.  pq_ctx_destroy detaches the plans still alive (frees their device tables):
+ * such a plan can only be handed to pq_plan_destroy any more, pq_plan_run and pq_plan_results
+ * return PQ_ERR_BAD_ARGUMENT for it.  The context keeps the device block of the largest plan
  * destroyed so far for the next plan to use, and frees it in pq_ctx_destroy. */
 typedef struct pq_plan pq_plan;
 
@@ -226,6 +237,22 @@ int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_valu
                 size_t dict_bytes);
 /* Waits for the stream and copies the per-page results to host memory. */
 int pq_plan_results(pq_plan *plan, pq_page_result *results);
+/* Diagnostics (no counterpart in the reference): how the last pq_plan_run treated the delta pages
+ * it cut into segments (PQ_OPT_SEGMENT_MAX_PAGES).  One record per segment, pages in plan order,
+ * a page's segments in stream order; *n_segments = how many there are, at most `cap` are copied
+ * (segs may be NULL with cap 0).  Waits for the stream. */
+typedef struct pq_segment_info {
+    uint32_t entry;   /* decode 1, 2: stream offset of the block header the segment starts at */
+    uint32_t exit;    /* where its walk of whole blocks reached the next segment; 0xffffffff: it did not */
+    uint32_t n_blocks;/* blocks walked */
+    uint32_t decode;  /* 0: decoded by a segment in front of it, serially; 1: by a wave of its own, up to
+                         the next such segment; 2: by a wave of its own, to the end of the page;
+                         3: the whole page by one wave (its segment 0) */
+    uint64_t value;   /* decode 1, 2: the value at position `position` */
+    uint32_t position;/* decode 1, 2: index in the page of the segment's first value */
+    uint32_t stop;    /* decode 1: stream offset of the block header it stops in front of */
+} pq_segment_info;
+int pq_plan_segments(pq_plan *plan, pq_segment_info *segs, size_t cap, size_t *n_segments);
 void pq_plan_destroy(pq_plan *plan);
 
 /* ---- batched decode from host memory ---------------------------------------
@@ -355,11 +382,20 @@ int pq_chunk_page_descs(const pq_chunk_desc *chunk, const pq_page_info *infos, u
                         uint64_t *dict_src, uint64_t *dict_dst, uint64_t *dict_bytes);
 
 /* The same for every walked chunk of a row group in one call.  infos: the table pq_walk_chunks
- * filled (chunk i's records at chunks[i].info_first, results[i].n_pages of them); chunks whose
- * walk failed are skipped (no descriptors).  descs: room for descs_cap descriptors
- * (PQ_ERR_OUT_OF_RANGE when they do not fit); first_desc: n_chunks + 1 entries, chunk i's
- * descriptors are descs[first_desc[i] .. first_desc[i + 1]); copies: room for n_chunks
- * dictionary copies (source offset in src, destination offset in the dictionary buffer, bytes). */
+ * filled (chunk i's records at chunks[i].info_first, results[i].n_pages of them).  descs: room for
+ * descs_cap descriptors; first_desc: n_chunks + 1 entries, chunk i's descriptors are
+ * descs[first_desc[i] .. first_desc[i + 1]); copies: room for n_chunks dictionary copies (source
+ * offset in src, destination offset in the dictionary buffer, bytes).
+ * Chunks are judged one by one: chunk_status[i] (n_chunks entries, may be NULL) is PQ_OK, the
+ * status of a failed walk (results[i].status), or what pq_chunk_page_descs returned for the chunk
+ * (PQ_ERR_BAD_ARGUMENT for compressed chunks and the types this library does not decode, such as
+ * a PLAIN BYTE_ARRAY column; PQ_UNEXPECTED_EOF for a dictionary page with too few bytes).  A chunk
+ * whose status is not PQ_OK gets no descriptors (first_desc[i + 1] == first_desc[i]), no dictionary
+ * copy and takes no room in `layout`; the other chunks are laid out as if it were not there, and the
+ * caller reads that column through the reference's own path.  first_desc[n_chunks] and *n_copies
+ * are always written.  Returns PQ_OK, PQ_ERR_BAD_ARGUMENT for missing arguments, or
+ * PQ_ERR_OUT_OF_RANGE when the descriptors do not fit descs_cap (the chunk that did not fit and
+ * all behind it carry that status and have no descriptors). */
 typedef struct pq_dict_copy {
     uint64_t src;
     uint64_t dst;
@@ -368,7 +404,8 @@ typedef struct pq_dict_copy {
 
 int pq_chunks_page_descs(const pq_chunk_desc *chunks, const pq_chunk_result *results, size_t n_chunks,
                          const pq_page_info *infos, pq_chunk_layout *layout, pq_page_desc *descs,
-                         size_t descs_cap, uint32_t *first_desc, pq_dict_copy *copies, uint32_t *n_copies);
+                         size_t descs_cap, uint32_t *first_desc, pq_dict_copy *copies, uint32_t *n_copies,
+                         int32_t *chunk_status);
 
 /* ---- Level post-processing: what the reference does with decoded levels, value by value ----
  *

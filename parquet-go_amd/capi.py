@@ -6,6 +6,7 @@ the library is missing or no HIP device is present the calls raise.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -25,6 +26,8 @@ BYTE_ARRAY_NEGATIVE_LEN, BYTE_ARRAY_COUNT_MISMATCH, BYTE_ARRAY_INVALID_PREFIX = 
 FLAG_LENGTH_PREFIXED, FLAG_LEVELS_CONST, FLAG_NO_INIT, FLAG_NO_LEVEL_OUTPUT = 1, 2, 4, 8
 OPT_DELTA_WAVE_MIN_PAGES = 1
 OPT_HYBRID_WAVE_MIN_PAGES = 2
+OPT_SEGMENT_MAX_PAGES = 3
+OPT_SEGMENT_BYTES = 4
 
 STAGE_NONE, STAGE_REP_INIT, STAGE_DEF_INIT, STAGE_VALUES_INIT, STAGE_REP, STAGE_DEF, STAGE_VALUES = range(7)
 
@@ -32,7 +35,7 @@ EXPORTS = [
     "pq_ctx_create", "pq_ctx_destroy", "pq_ctx_synchronize", "pq_ctx_set_option", "pq_status_string",
     "pq_last_error",
     "pq_version", "pq_bitunpack32_dev", "pq_bitunpack64_dev", "pq_bitunpack32", "pq_bitunpack64",
-    "pq_plan_create", "pq_plan_run", "pq_plan_results", "pq_plan_destroy", "pq_decode_pages",
+    "pq_plan_create", "pq_plan_run", "pq_plan_results", "pq_plan_segments", "pq_plan_destroy", "pq_decode_pages",
     "pq_hybrid_decode", "pq_dict_decode", "pq_levels_decode", "pq_delta_decode32",
     "pq_delta_decode64", "pq_plain_decode", "pq_bool_plain_decode",
     "pq_levels_pack_dev", "pq_levels_pack", "pq_column_entries_dev", "pq_column_entries", "pq_column_entries_noalloc",
@@ -124,6 +127,7 @@ def load():
         lib.pq_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         lib.pq_plan_results.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pq_plan_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         lib.pq_decode_pages.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_size_t, C.c_void_p]
@@ -161,7 +165,7 @@ def load():
         lib.pq_chunk_page_descs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pq_chunks_page_descs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
-                                             C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+                                             C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -198,9 +202,12 @@ class Context:
         if st != OK:
             raise PqError(st, "(pq_ctx_create)")
         self._h = h
+        self._plans = weakref.WeakSet()
 
     def close(self):
         if self._h:
+            for p in list(self._plans):     # plans go before their context
+                p.close()
             self._lib.pq_ctx_destroy(self._h)
             self._h = None
 
@@ -398,7 +405,9 @@ class Context:
         return res[:ch.size]
 
     def plan(self, descs):
-        return Plan(self, descs)
+        p = Plan(self, descs)
+        self._plans.add(p)
+        return p
 
 
 def chunk_page_descs(chunk, infos, layout):
@@ -447,6 +456,17 @@ class Plan:
             raise PqError(st, "(pq_plan_results) " + self._lib.pq_last_error(self._ctx._h).decode())
         return out
 
+    def segments(self):
+        """pq_plan_segments: one SEGMENT_DTYPE record per segment of the delta pages cut into segments."""
+        n = C.c_size_t(0)
+        st = self._lib.pq_plan_segments(self._h, None, 0, C.byref(n))
+        out = np.zeros(n.value, dtype=SEGMENT_DTYPE)
+        if st == OK and n.value:
+            st = self._lib.pq_plan_segments(self._h, _ptr(out), n.value, C.byref(n))
+        if st != OK:
+            raise PqError(st, "(pq_plan_segments) " + self._lib.pq_last_error(self._ctx._h).decode())
+        return out
+
     def close(self):
         if self._h:
             self._lib.pq_plan_destroy(self._h)
@@ -459,23 +479,33 @@ class Plan:
             pass
 
 
+SEGMENT_DTYPE = np.dtype([("entry", "<u4"), ("exit", "<u4"), ("n_blocks", "<u4"), ("decode", "<u4"),
+                          ("value", "<u8"), ("position", "<u4"), ("stop", "<u4")])
 DICT_COPY_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("bytes", "<u8")])
 
 
-def chunks_page_descs(chunks, results, infos, layout):
+def chunks_page_descs(chunks, results, infos, layout, with_status=False, descs_cap=None):
     """pq_chunks_page_descs: descriptors for every walked chunk in one call.
-    -> (descs, first_desc[n_chunks + 1], dictionary copies)"""
+    -> (descs, first_desc[n_chunks + 1], dictionary copies[, per-chunk status, return code])
+    Without with_status any chunk the library cannot describe raises, as does a full table."""
     lib = load()
     ch = np.ascontiguousarray(chunks, dtype=CHUNK_DTYPE)
     res = np.ascontiguousarray(results, dtype=CHUNK_RESULT_DTYPE)
     inf = np.ascontiguousarray(infos, dtype=PAGE_INFO_DTYPE)
-    cap = int(res["n_pages"].sum())
+    cap = int(res["n_pages"].sum()) if descs_cap is None else int(descs_cap)
     descs = np.zeros(max(cap, 1), dtype=DESC_DTYPE)
     first = np.zeros(ch.size + 1, dtype=np.uint32)
     copies = np.zeros(max(ch.size, 1), dtype=DICT_COPY_DTYPE)
+    status = np.zeros(max(ch.size, 1), dtype=np.int32)
     nc = C.c_uint32(0)
     st = lib.pq_chunks_page_descs(_ptr(ch), _ptr(res), ch.size, _ptr(inf), _ptr(layout), _ptr(descs), cap,
-                                  _ptr(first), _ptr(copies), C.byref(nc))
+                                  _ptr(first), _ptr(copies), C.byref(nc), _ptr(status))
+    status = status[:ch.size]
+    if with_status:
+        return descs[:int(first[-1])], first, copies[:nc.value], status, st
     if st != OK:
         raise PqError(st, "(pq_chunks_page_descs) " + status_string(st))
+    bad = np.flatnonzero(status != OK)
+    if bad.size:
+        raise PqError(int(status[bad[0]]), "(pq_chunks_page_descs) chunk %d: %s" % (bad[0], status_string(status[bad[0]])))
     return descs[:int(first[-1])], first, copies[:nc.value]

@@ -24,6 +24,10 @@ struct pq_ctx {
     // measured on MI355X: the wave kernels are at least as fast from a single page on
     uint32_t delta_wave_min_pages = 1;
     uint32_t hybrid_wave_min_pages = 1;
+    // delta pages are cut into segments when a plan has fewer than seg_max_pages of one element
+    // size; seg_bytes != 0 fixes the segment length (else it follows the plan's size)
+    uint32_t seg_max_pages = 2048;
+    uint32_t seg_bytes = 0;
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_cap[4] = {0, 0, 0, 0};
     // grow-only scratch of the device-pointer entry points that need one
@@ -38,6 +42,8 @@ struct pq_ctx {
     size_t host_img_cap[2] = {0, 0};
     hipEvent_t host_img_done[2] = {nullptr, nullptr};  // recorded behind the copy out of the image
     unsigned host_img_next = 0;
+    // plans made from this context and not yet destroyed: pq_ctx_destroy detaches them
+    std::vector<pq_plan *> live_plans;
 };
 
 struct pq_plan {
@@ -58,6 +64,13 @@ struct pq_plan {
     uint32_t shared_dict_bytes = 0;
     uint64_t shared_dict_off = 0;
     bool has_delta_page = false; // some PAGE_V1/V2 descriptor carries delta values
+    // delta32 / delta64 descriptors that are decoded in segments: the last n_seg_pages[k] ids of
+    // group 1 + k, their page records, the segment -> page map and the segment records
+    uint32_t n_seg_pages[2] = {0, 0};
+    uint32_t n_segs[2] = {0, 0};
+    pq::SegPage *d_seg_pages[2] = {nullptr, nullptr};
+    uint32_t *d_seg_owner[2] = {nullptr, nullptr};
+    pq::SegRec *d_seg_recs[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -168,7 +181,7 @@ int ensure_stage(pq_ctx *ctx, int slot, size_t bytes)
 
 extern "C" {
 
-int pq_version(void) { return 100; }
+int pq_version(void) { return 101; }
 
 const char *pq_status_string(int s)
 {
@@ -256,6 +269,13 @@ void pq_ctx_destroy(pq_ctx *ctx)
     for (int i = 0; i < 4; ++i)
         if (ctx->stage[i]) (void)hipFree(ctx->stage[i]);
     if (ctx->work) (void)hipFree(ctx->work);
+    // plans that outlive their context lose their device block here; what is left of them is a
+    // host record that pq_plan_destroy deletes and every other call refuses
+    for (pq_plan *p : ctx->live_plans) {
+        if (p->d_descs) (void)hipFree(p->d_descs);
+        p->d_descs = nullptr;
+        p->ctx = nullptr;
+    }
     if (ctx->spare_block) (void)hipFree(ctx->spare_block);
     for (int i = 0; i < 2; ++i) {
         if (ctx->host_img[i]) (void)hipHostFree(ctx->host_img[i]);
@@ -284,6 +304,15 @@ int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value)
     case PQ_OPT_HYBRID_WAVE_MIN_PAGES:
         if (value < 0) return PQ_ERR_BAD_ARGUMENT;
         ctx->hybrid_wave_min_pages = value > 0xffffffffll ? 0xffffffffu : (uint32_t)value;
+        return PQ_OK;
+    case PQ_OPT_SEGMENT_MAX_PAGES:
+        if (value < 0) return PQ_ERR_BAD_ARGUMENT;
+        ctx->seg_max_pages = value > 0xffffffffll ? 0xffffffffu : (uint32_t)value;
+        return PQ_OK;
+    case PQ_OPT_SEGMENT_BYTES:
+        // a segment holds at least one block header (a 256-value block is at most 1038 bytes)
+        if (value != 0 && (value < 2048 || value > (1ll << 24) || (value & 15) != 0)) return PQ_ERR_BAD_ARGUMENT;
+        ctx->seg_bytes = (uint32_t)value;
         return PQ_OK;
     default: return PQ_ERR_BAD_ARGUMENT;
     }
@@ -433,6 +462,39 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
         if (mixed)
             std::stable_sort(ids[g].begin(), ids[g].end(), [&](uint32_t a, uint32_t b) { return bucket[a] > bucket[b]; });
     }
+    // Few delta pages of one element size cannot fill the machine one wave a page: the large
+    // ones among them are cut into segments by bytes (segdelta.hip) and go behind the others.
+    std::vector<pq::SegPage> seg_pages[2];
+    std::vector<uint32_t> seg_owner[2];
+    for (int k = 0; k < 2; ++k) {
+        std::vector<uint32_t> &g = ids[1 + k];
+        if (g.empty() || g.size() >= ctx->seg_max_pages) continue;
+        uint64_t bytes = 0;
+        for (uint32_t i : g) bytes += descs[i].src_len;
+        uint64_t L = ctx->seg_bytes;
+        if (L == 0) {
+            L = 8192;  // about 8192 segments in flight, between 8 and 64 KiB each
+            while (L < 65536 && L * 8192 < bytes) L *= 2;
+        }
+        auto cut = [&](uint32_t i) {
+            const pq_page_desc &d = descs[i];
+            return d.src_len >= 3 * L && d.src_len < 0x7fffffffull && d.n_values >= 1024u;
+        };
+        std::stable_partition(g.begin(), g.end(), [&](uint32_t i) { return !cut(i); });
+        for (uint32_t i : g) {
+            if (!cut(i)) continue;
+            pq::SegPage pg;
+            std::memset(&pg, 0, sizeof pg);
+            pg.desc = i;
+            pg.seg_first = (uint32_t)seg_owner[k].size();
+            pg.n_segs = (uint32_t)((descs[i].src_len + L - 1) / L);
+            pg.seg_bytes = (uint32_t)L;
+            seg_owner[k].insert(seg_owner[k].end(), pg.n_segs, (uint32_t)seg_pages[k].size());
+            seg_pages[k].push_back(pg);
+        }
+        plan->n_seg_pages[k] = (uint32_t)seg_pages[k].size();
+        plan->n_segs[k] = (uint32_t)seg_owner[k].size();
+    }
     std::vector<uint32_t> all;
     all.reserve(n_pages);
     for (int g = 0; g < 4; ++g) {
@@ -442,12 +504,21 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
     }
     if (n_pages) {
         // one block: descriptors | ids | wake-up words (uint32 [0], [32], [64], each on a 128-byte
-        // line of its own) | results.  Everything in front of the results is put together in a
-        // pinned host image and goes over in one copy.
+        // line of its own) | segment page records and segment -> page maps | results | segment
+        // records.  Everything in front of the results is put together in a pinned host image and
+        // goes over in one copy.
         constexpr size_t kFlagBytes = 512;
-        const size_t db = (n_pages * sizeof(pq_page_desc) + 255) / 256 * 256, rb = n_pages * sizeof(pq_page_result);
-        const size_t ib = (n_pages * sizeof(uint32_t) + 255) / 256 * 256;
-        const size_t img = db + ib + kFlagBytes, total = img + rb;
+        auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+        const size_t db = up(n_pages * sizeof(pq_page_desc)), rb = up(n_pages * sizeof(pq_page_result));
+        const size_t ib = up(n_pages * sizeof(uint32_t));
+        size_t spb[2], sob[2], srb[2];
+        for (int k = 0; k < 2; ++k) {
+            spb[k] = up(seg_pages[k].size() * sizeof(pq::SegPage));
+            sob[k] = up(seg_owner[k].size() * sizeof(uint32_t));
+            srb[k] = up(seg_owner[k].size() * sizeof(pq::SegRec));
+        }
+        const size_t img = db + ib + kFlagBytes + spb[0] + sob[0] + spb[1] + sob[1];
+        const size_t total = img + rb + srb[0] + srb[1];
         uint8_t *block = nullptr;
         hipError_t e = hipSuccess;
         if (ctx->spare_block && ctx->spare_bytes >= total) {
@@ -481,19 +552,31 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
             std::memcpy(h, descs, n_pages * sizeof(pq_page_desc));
             std::memcpy(h + db, all.data(), n_pages * sizeof(uint32_t));
             std::memset(h + db + n_pages * sizeof(uint32_t), 0, ib - n_pages * sizeof(uint32_t) + kFlagBytes);
+            size_t at = db + ib + kFlagBytes, rec_at = img + rb;
+            for (int k = 0; k < 2; ++k) {
+                plan->d_seg_pages[k] = reinterpret_cast<pq::SegPage *>(block + at);
+                if (!seg_pages[k].empty()) std::memcpy(h + at, seg_pages[k].data(), seg_pages[k].size() * sizeof(pq::SegPage));
+                at += spb[k];
+                plan->d_seg_owner[k] = reinterpret_cast<uint32_t *>(block + at);
+                if (!seg_owner[k].empty()) std::memcpy(h + at, seg_owner[k].data(), seg_owner[k].size() * sizeof(uint32_t));
+                at += sob[k];
+                plan->d_seg_recs[k] = reinterpret_cast<pq::SegRec *>(block + rec_at);
+                rec_at += srb[k];
+            }
             e = hipMemcpyAsync(block, h, img, hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess) e = hipEventRecord(ctx->host_img_done[slot], ctx->stream);
         } else if (block) {
             plan->d_descs = reinterpret_cast<pq_page_desc *>(block);  // for pq_plan_destroy
         }
         // nothing waits here: the tables are on their way on the stream the plan runs on
-        if (e == hipSuccess) e = hipMemsetAsync(plan->d_results, 0xff, rb, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(plan->d_results, 0xff, n_pages * sizeof(pq_page_result), ctx->stream);
         if (e != hipSuccess) {
             hip_ok(ctx, e, "pq_plan_create");
             pq_plan_destroy(plan);
             return PQ_ERR_HIP;
         }
     }
+    ctx->live_plans.push_back(plan);
     *out = plan;
     return PQ_OK;
 }
@@ -501,6 +584,14 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
 void pq_plan_destroy(pq_plan *plan)
 {
     if (!plan) return;
+    if (!plan->ctx) {  // its context went first and took the device block with it
+        delete plan;
+        return;
+    }
+    {
+        std::vector<pq_plan *> &lp = plan->ctx->live_plans;
+        lp.erase(std::remove(lp.begin(), lp.end(), plan), lp.end());
+    }
     (void)hipSetDevice(plan->ctx->device);
     (void)hipStreamSynchronize(plan->ctx->stream);
     if (plan->d_descs) {  // one block holds ids, results and flags too
@@ -519,7 +610,7 @@ void pq_plan_destroy(pq_plan *plan)
 int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_values, size_t values_bytes,
                 void *d_levels, size_t levels_bytes, const void *d_dict, size_t dict_bytes)
 {
-    if (!plan) return PQ_ERR_BAD_ARGUMENT;
+    if (!plan || !plan->ctx) return PQ_ERR_BAD_ARGUMENT;  // no context: it was destroyed before the plan
     pq_ctx *ctx = plan->ctx;
     if (plan->n == 0) return PQ_OK;
     if (plan->src_need > src_bytes || plan->values_need > values_bytes ||
@@ -541,12 +632,17 @@ int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_valu
     plan->epoch += 1;
     if (plan->epoch == 0) plan->epoch = 1; // 0 is what the flag words start as
     bool serial32 = false, serial64 = false;
+    for (int k = 0; k < 2; ++k)  // the pages cut into segments first: they are the long ones
+        PQ_HIP(ctx, pq::launch_seg_delta(ctx->stream, k ? 64 : 32, plan->d_descs, plan->d_seg_pages[k],
+                                         plan->n_seg_pages[k], plan->d_seg_owner[k], plan->n_segs[k],
+                                         plan->d_seg_recs[k], buf, plan->d_results, plan->d_flags + 32 * k,
+                                         plan->epoch));
     PQ_HIP(ctx, pq::launch_delta_pages(ctx->stream, 32, plan->d_descs, plan->d_ids + plan->first[1],
-                                       plan->count[1], buf, plan->d_results, ctx->delta_wave_min_pages,
-                                       plan->d_flags, plan->epoch, &serial32));
+                                       plan->count[1] - plan->n_seg_pages[0], plan->count[1], buf, plan->d_results,
+                                       ctx->delta_wave_min_pages, plan->d_flags, plan->epoch, &serial32));
     PQ_HIP(ctx, pq::launch_delta_pages(ctx->stream, 64, plan->d_descs, plan->d_ids + plan->first[2],
-                                       plan->count[2], buf, plan->d_results, ctx->delta_wave_min_pages,
-                                       plan->d_flags + 32, plan->epoch, &serial64));
+                                       plan->count[2] - plan->n_seg_pages[1], plan->count[2], buf, plan->d_results,
+                                       ctx->delta_wave_min_pages, plan->d_flags + 32, plan->epoch, &serial64));
     PQ_HIP(ctx, pq::launch_data_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[3],
                                       plan->count[3], buf, plan->d_results, plan->dict_lds_bytes, wl,
                                       plan->d_flags + 64, plan->epoch));
@@ -561,13 +657,32 @@ int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_valu
 
 int pq_plan_results(pq_plan *plan, pq_page_result *results)
 {
-    if (!plan || (plan->n && !results)) return PQ_ERR_BAD_ARGUMENT;
+    if (!plan || !plan->ctx || (plan->n && !results)) return PQ_ERR_BAD_ARGUMENT;
     pq_ctx *ctx = plan->ctx;
     PQ_HIP(ctx, hipSetDevice(ctx->device));
     PQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (plan->n)
         PQ_HIP(ctx, hipMemcpy(results, plan->d_results, plan->n * sizeof(pq_page_result),
                               hipMemcpyDeviceToHost));
+    return PQ_OK;
+}
+
+static_assert(sizeof(pq_segment_info) == sizeof(pq::SegRec), "pq_segment_info is the device record");
+
+int pq_plan_segments(pq_plan *plan, pq_segment_info *segs, size_t cap, size_t *n_segments)
+{
+    if (!plan || !plan->ctx || !n_segments || (cap && !segs)) return PQ_ERR_BAD_ARGUMENT;
+    pq_ctx *ctx = plan->ctx;
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    PQ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_segments = (size_t)plan->n_segs[0] + plan->n_segs[1];
+    size_t done = 0;
+    for (int k = 0; k < 2 && done < cap; ++k) {
+        const size_t take = std::min<size_t>(plan->n_segs[k], cap - done);
+        if (take)
+            PQ_HIP(ctx, hipMemcpy(segs + done, plan->d_seg_recs[k], take * sizeof(pq_segment_info), hipMemcpyDeviceToHost));
+        done += take;
+    }
     return PQ_OK;
 }
 
@@ -965,28 +1080,47 @@ int pq_chunk_page_descs(const pq_chunk_desc *chunk, const pq_page_info *infos, u
 
 int pq_chunks_page_descs(const pq_chunk_desc *chunks, const pq_chunk_result *results, size_t n_chunks,
                          const pq_page_info *infos, pq_chunk_layout *layout, pq_page_desc *descs, size_t descs_cap,
-                         uint32_t *first_desc, pq_dict_copy *copies, uint32_t *n_copies)
+                         uint32_t *first_desc, pq_dict_copy *copies, uint32_t *n_copies, int32_t *chunk_status)
 {
     if (!layout || !first_desc || !n_copies || (n_chunks && (!chunks || !results || !infos || !copies)))
         return PQ_ERR_BAD_ARGUMENT;
     size_t out = 0;
     uint32_t nc = 0;
+    int rc = PQ_OK;
     for (size_t i = 0; i < n_chunks; ++i) {
         first_desc[i] = (uint32_t)out;
-        if (results[i].status != PQ_OK) continue;
+        if (rc != PQ_OK) {  // the table is full: the chunks behind get no descriptors
+            if (chunk_status) chunk_status[i] = PQ_ERR_OUT_OF_RANGE;
+            continue;
+        }
+        if (results[i].status != PQ_OK) {
+            if (chunk_status) chunk_status[i] = results[i].status;
+            continue;
+        }
         const uint32_t np = results[i].n_pages;
-        if (out + np > descs_cap || (np && !descs)) return PQ_ERR_OUT_OF_RANGE;
+        if (out + np > descs_cap || (np && !descs)) {
+            rc = PQ_ERR_OUT_OF_RANGE;
+            if (chunk_status) chunk_status[i] = PQ_ERR_OUT_OF_RANGE;
+            continue;
+        }
         uint32_t made = 0;
         pq_dict_copy c{0, 0, 0};
+        const pq_chunk_layout before = *layout;
         const int st = pq_chunk_page_descs(&chunks[i], infos + chunks[i].info_first, np, layout, descs + out, &made,
                                            &c.src, &c.dst, &c.bytes);
-        if (st != PQ_OK) return st;
+        if (chunk_status) chunk_status[i] = st;
+        if (st != PQ_OK) {
+            // a chunk this library does not decode (or a damaged dictionary page): no descriptors,
+            // no room taken, the other chunks of the row group go on
+            *layout = before;
+            continue;
+        }
         out += made;
         if (c.bytes) copies[nc++] = c;
     }
     first_desc[n_chunks] = (uint32_t)out;
     *n_copies = nc;
-    return PQ_OK;
+    return rc;
 }
 
 // ---- level post-processing ----------------------------------------------------

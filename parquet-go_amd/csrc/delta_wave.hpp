@@ -30,6 +30,7 @@ constexpr int kDwStride = kDwChunk - kDwBlockMax; // distance between consecutiv
 constexpr int kDwPieces = kDwChunk / 16 / kWave; // 16-byte pieces per lane
 constexpr int32_t kNeedGeneric = -2;
 constexpr int32_t kOverCap = -3;  // the stream declares more values than the caller's `cap`
+constexpr int32_t kSegStopped = -4; // a segment decode reached the block header it was told to stop at
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -436,17 +437,22 @@ struct WaveDeltaResult {
 
 // The tiles of one page behind its stream header (pos = the first block header, first = the first
 // value, the window [c0, c0 + kDwChunk) staged).  LG = log2 of the values per miniblock.
-template <typename UT, uint32_t LG, bool OFFS = false>
+// SEG: the decode starts in the middle of the page, at the block header at `pos` whose first value
+// has position seg_p0 (a multiple of the block size) and is `first`, and ends in front of the
+// block header at stream offset seg_stop (status kSegStopped; < 0: runs to the end of the page
+// like the whole-page decode, tail rules, status and consumed bytes included).
+template <typename UT, uint32_t LG, bool OFFS = false, bool SEG = false>
 __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const uint8_t *S, int64_t len, uint32_t n,
                                                             UT *dst, int lane, WavePrefetch &pf, int64_t c0, int64_t pos,
                                                             uint32_t total32, uint64_t first, bool vec_ok,
-                                                            WaveOffsets *wo = nullptr)
+                                                            WaveOffsets *wo = nullptr, uint32_t seg_p0 = 0,
+                                                            int64_t seg_stop = -1)
 {
     WaveDeltaResult res{PQ_OK, 0, 0, 0, total32};
     WaveState<UT> st;
     st.pos = pos;
     st.end_pos = pos;
-    st.tiles_done = 0;
+    st.tiles_done = SEG ? seg_p0 >> 7 : 0u;
     st.total = total32;
     st.need = min(n, total32);
     st.n_ok = 0;
@@ -481,7 +487,8 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
     ln.k2 = (2u * (uint32_t)lane) & ((1u << LG) - 1u);
     UT carry = (UT)first;
     uint32_t o = (uint32_t)(pos - c0); // window offset of the next block header
-    uint32_t p0 = 0;                   // position of that block's first value
+    uint32_t p0 = SEG ? seg_p0 : 0u;   // position of that block's first value
+    bool stopped = false;
     while (true) {
         // The window [c0, c0 + kDwChunk) is in LDS.  Windows advance by a fixed stride
         // (a block never needs more than kDwBlockMax bytes, so whatever block straddles
@@ -493,6 +500,12 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
         const int64_t left = len - c0;
         const uint32_t lim = left > (int64_t)kDwChunk ? (uint32_t)kDwChunk : (left < 0 ? 0u : (uint32_t)left);
         while (!st.finished && (tail || o + (uint32_t)kDwBlockMax <= (uint32_t)kDwChunk)) {
+            if constexpr (SEG) {
+                if (seg_stop >= 0 && (LG == 5u || blk.half == 0u) && c0 + (int64_t)o >= seg_stop) {
+                    stopped = true;
+                    break;
+                }
+            }
             WaveTile t = wave_tile_none();
             if (wave_walk_fast<LG>(t, lds, o, lim, p0, st.need, blk)) {
                 wave_decode_tile<UT, false, LG, OFFS>(lds, t, carry, dst, 0xffffffffu, vec_ok, lane, ln, wo);
@@ -519,7 +532,7 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
             const uint32_t clip = st.finished ? st.n_ok : 0xffffffffu;
             if (t.valid) wave_decode_tile<UT, true, LG, OFFS>(lds, t, carry, dst, clip, vec_ok, lane, ln, wo);
         }
-        if (st.finished) break;
+        if (st.finished || stopped) break;
         wave_sync();
         wave_commit(lds, pf, lane);
         wave_sync();
@@ -527,6 +540,10 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
         o -= (uint32_t)kDwStride;
     }
 
+    if (SEG && stopped) {
+        res.status = kSegStopped;
+        return res;
+    }
     res.status = st.status;
     res.n_decoded = st.n_ok;
     res.init_failed = st.init_failed;

@@ -994,32 +994,34 @@ hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const
 }
 
 hipError_t launch_delta_pages(hipStream_t s, int bits, const pq_page_desc *d_descs, const uint32_t *d_ids,
-                              uint32_t count, PageBuffers buf, pq_page_result *d_results,
+                              uint32_t count, uint32_t sweep_count, PageBuffers buf, pq_page_result *d_results,
                               uint32_t wave_min_pages, uint32_t *d_flag, uint32_t epoch, bool *needs_serial)
 {
     *needs_serial = false;
-    if (count == 0) return hipSuccess;
+    if (sweep_count == 0) return hipSuccess;
     // Enough pages to fill the chip with one wave each (256 CUs x 8 waves and up): the
     // barrier-free wave-per-page kernel first, then a sweep by the workgroup-per-page
     // kernel over the pages whose layout is not 128 / 4 (normally none: it ends after
     // reading one flag word).  Few, large pages go to the workgroup-per-page kernel directly.
-    if (count >= wave_min_pages) {
+    if (count >= wave_min_pages || sweep_count > count) {
         const uint32_t grid = (count + kWG / kWave - 1) / (kWG / kWave);
-        if (bits == 64)
-            hipLaunchKernelGGL(delta_wave_kernel<uint64_t>, dim3(grid), dim3(kWG), 0, s, d_descs, d_ids, count,
-                               buf, d_results, d_flag, epoch);
-        else
-            hipLaunchKernelGGL(delta_wave_kernel<uint32_t>, dim3(grid), dim3(kWG), 0, s, d_descs, d_ids, count,
-                               buf, d_results, d_flag, epoch);
+        if (count != 0) {
+            if (bits == 64)
+                hipLaunchKernelGGL(delta_wave_kernel<uint64_t>, dim3(grid), dim3(kWG), 0, s, d_descs, d_ids, count,
+                                   buf, d_results, d_flag, epoch);
+            else
+                hipLaunchKernelGGL(delta_wave_kernel<uint32_t>, dim3(grid), dim3(kWG), 0, s, d_descs, d_ids, count,
+                                   buf, d_results, d_flag, epoch);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
-        const uint32_t sweep = min(count, 256u);
+        const uint32_t sweep = min(sweep_count, 256u);
         if (bits == 64)
             hipLaunchKernelGGL((delta_pages_kernel<uint64_t, true>), dim3(sweep), dim3(kWG), 0, s, d_descs, d_ids,
-                               count, buf, d_results, d_flag, epoch);
+                               sweep_count, buf, d_results, d_flag, epoch);
         else
             hipLaunchKernelGGL((delta_pages_kernel<uint32_t, true>), dim3(sweep), dim3(kWG), 0, s, d_descs, d_ids,
-                               count, buf, d_results, d_flag, epoch);
+                               sweep_count, buf, d_results, d_flag, epoch);
         return hipGetLastError();
     }
     *needs_serial = true;

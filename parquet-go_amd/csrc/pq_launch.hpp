@@ -39,8 +39,10 @@ hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const
 // wave_min_pages: from this many pages on, the one-wave-per-page kernel runs first and a
 // sweep kernel (woken through *d_flag == epoch) finishes the pages it declined.
 // *needs_serial: launch_delta_serial must follow for these descriptors.
+// The sweep looks at ids[0 .. sweep_count): the pages of this launch and, behind them, the pages
+// launch_seg_delta decoded.
 hipError_t launch_delta_pages(hipStream_t s, int bits, const pq_page_desc *d_descs,
-                              const uint32_t *d_ids, uint32_t count, PageBuffers buf,
+                              const uint32_t *d_ids, uint32_t count, uint32_t sweep_count, PageBuffers buf,
                               pq_page_result *d_results, uint32_t wave_min_pages, uint32_t *d_flag,
                               uint32_t epoch, bool *needs_serial);
 hipError_t launch_data_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
@@ -53,6 +55,39 @@ hipError_t launch_delta_serial(hipStream_t s, const pq_page_desc *d_descs, const
                                uint32_t count, PageBuffers buf, pq_page_result *d_results);
 
 constexpr uint32_t kDictLdsMax = 48u * 1024u;
+
+// ---- segmented delta pages (segdelta.hip) -------------------------------------------------------
+// One record per page that is cut into segments.  The host fills desc, seg_first, n_segs and
+// seg_bytes; the rest is written on the device every run.
+struct SegPage {
+    uint32_t desc;       // index of the page's descriptor
+    uint32_t seg_first;  // index of its first segment record
+    uint32_t n_segs;
+    uint32_t seg_bytes;  // bytes of the stream per segment
+    uint32_t whole;      // 1: unusual stream header, segment 0 decodes the whole page
+    uint32_t lg;         // log2 of the values per miniblock: 5 (128 / 4) or 6 (256 / 4)
+    uint32_t total;      // value count the stream declares
+    uint32_t pos0;       // stream offset of the first block header
+    uint64_t first;      // first value
+};
+// One record per segment, written on the device.
+constexpr uint32_t kSegSkip = 0, kSegPart = 1, kSegTail = 2, kSegWhole = 3;
+struct SegRec {
+    uint32_t entry;  // scan: guessed stream offset of the first block's width bytes (0xffffffff: none);
+                     // linked: stream offset of that block's header
+    uint32_t exit;   // header of the first block of the next segment, reached by walking whole blocks
+    uint32_t nblk;   // blocks walked
+    uint32_t flags;  // kSeg*: what the decode does with the segment
+    uint64_t sum;    // scan: sum of the walked blocks' deltas without the first block's minDelta;
+                     // linked: the value at position p0
+    uint32_t p0;     // scan: stream offset of the width bytes of the header at `exit`;
+                     // linked: position of the segment's first value
+    uint32_t stop;   // scan: minDelta of the header at `exit`; linked, kSegPart: stream offset to stop in front of
+};
+// d_pages / d_owner (segment -> index into d_pages) / d_recs: n_pages, n_segs, n_segs entries.
+hipError_t launch_seg_delta(hipStream_t s, int bits, const pq_page_desc *d_descs, SegPage *d_pages, uint32_t n_pages,
+                            const uint32_t *d_owner, uint32_t n_segs, SegRec *d_recs, PageBuffers buf,
+                            pq_page_result *d_results, uint32_t *d_flag, uint32_t epoch);
 
 // Level post-processing (assemble.hip).  d_out: ceil(n / 8) * w bytes, 4-byte aligned.
 hipError_t launch_levels_pack(hipStream_t s, const int32_t *d_levels, uint64_t n, int w, uint8_t *d_out);

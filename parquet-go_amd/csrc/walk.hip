@@ -533,8 +533,10 @@ __global__ __launch_bounds__(kWkWaves *kWave) void walk_chunks_kernel(const pq_c
                                                                      pq_page_info *__restrict__ infos,
                                                                      pq_chunk_result *__restrict__ results)
 {
-    __shared__ uint32_t s_win[kWkWaves][kWkWin / 4 + 64];  // slack: the fast path loads 64 dwords from any window offset
-    __shared__ uint32_t s_frames[kWkWaves][2 * kWkDepth];
+    // rows are written with 16-byte LDS stores: the array and every row start on 16-byte boundaries
+    static_assert((kWkWin / 4 + 64) % 4 == 0, "a window row must be a whole number of 16-byte pieces");
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[kWkWaves][kWkWin / 4 + 64];  // slack: the fast path loads 64 dwords from any window offset
+    __shared__ __attribute__((aligned(16))) uint32_t s_frames[kWkWaves][2 * kWkDepth];
     const int wave = (int)uni(threadIdx.x / kWave), lane = (int)(threadIdx.x % kWave);
     const uint32_t ci = blockIdx.x * kWkWaves + (uint32_t)wave;
     if (ci >= n_chunks) return;

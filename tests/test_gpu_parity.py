@@ -715,3 +715,25 @@ def test_plans_side_by_side_and_one_after_another(ctx):
     e.run(a[1].data_ptr(), a[1].numel(), a[2].data_ptr(), a[2].numel())
     check(e, a[1], a[2], a[3], 300)
     e.close()
+
+
+# ---------------------------------------------------------------------------
+# The CPU reference configuration as worded: INT32 RLE_DICTIONARY, bit width 12, 1 M values
+
+def test_c1_dictionary_column_width_12(ctx):
+    """4096-entry int32 dictionary (low 32 bits of splitmix64, seed 0xD1C7), 1 M keys uniform in
+    [0, 4096) (seed 1) written by the reference encoder's algorithm at width 12: as one 1 M-value
+    PQ_KIND_DICT page and as 50 pages of 20 000 values, every value against the oracle."""
+    d = synth.splitmix64(0xD1C7, 4096).astype(np.uint32).view(np.int32)
+    keys = (synth.splitmix64(1, 1_000_000) % np.uint64(4096)).astype(np.int64)
+    pages = [keys] + [keys[p * 20000:(p + 1) * 20000] for p in range(50)]
+    cases = [Case(K.KIND_DICT, synth.dict_page(k, w=12), k.size, dictionary=d) for k in pages]
+    assert all(c.src[0] == 12 for c in cases)
+    run_cases(ctx, cases, seed=12)
+    for c, k in zip(cases, pages):
+        st, want, nd, consumed = O.dict_decode(c.src, d, k.size)
+        assert st == O.OK and nd == k.size
+        assert c.result["status"] == K.OK and c.result["n_decoded"] == k.size
+        assert c.result["consumed"] == consumed
+        assert np.array_equal(c.values, want) and np.array_equal(want, d[k])
+        assert guard_ok(c.guard)

@@ -1,0 +1,208 @@
+"""GPU parity of the segmented DELTA_BINARY_PACKED decode (many waves to one page) against the CPU
+oracle: values, status, counts and consumed bytes must be those of the whole-page decode, whatever
+the segment length, wherever the stream is cut, and also when the guessed segment starts are wrong.
+Reference: encoding/delta-binary-packed-decoder.go:29-170 (a page is one chain of blocks)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from gpu_harness import Case, guard_ok, run_cases
+from parquet_go_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+K = capi
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _check(c, bits):
+    want = (O.delta_decode32 if bits == 32 else O.delta_decode64)(c.src[: c.result_src_len], c.n)
+    r = c.result
+    assert r["status"] == want["status"], (bits, c.n, c.result_src_len, r, want["status"], want["n_decoded"])
+    assert r["n_decoded"] == want["n_decoded"], (bits, c.n, c.result_src_len, r, want["n_decoded"])
+    got = c.values[: want["n_decoded"]]
+    if not np.array_equal(got, want["values"]):
+        bad = int(np.flatnonzero(got != want["values"])[0])
+        raise AssertionError((bits, c.n, c.result_src_len, "first difference at", bad, got[bad], want["values"][bad]))
+    assert guard_ok(c.guard)
+    if want["status"] == O.OK:
+        assert r["consumed"] == want["consumed"], (bits, c.n, c.result_src_len)
+
+
+def _run(ctx, cases, bits, seg_bytes, seed=0):
+    """The same cases cut into segments of seg_bytes and not cut at all."""
+    try:
+        for max_pages, sb in ((1 << 30, seg_bytes), (0, 0)):
+            ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, max_pages)
+            ctx.set_option(K.OPT_SEGMENT_BYTES, sb)
+            run_cases(ctx, cases, seed=seed)
+            for c in cases:
+                _check(c, bits)
+    finally:
+        ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 2048)
+        ctx.set_option(K.OPT_SEGMENT_BYTES, 0)
+
+
+def _values(rng, n, wmax, dt, base=None):
+    steps = rng.integers(0, 1 << wmax, size=n) if wmax else np.zeros(n, np.int64)
+    base = int(rng.integers(-1000, 1000)) if base is None else base
+    with np.errstate(over="ignore"):
+        return (np.cumsum(steps + base) + int(rng.integers(-2**40, 2**40))).astype(dt)
+
+
+def _case(bits, stream, n):
+    c = Case(K.KIND_DELTA32 if bits == 32 else K.KIND_DELTA64, stream, n)
+    c.result_src_len = stream.size
+    return c
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+@pytest.mark.parametrize("seg_bytes", [2048, 4096, 16384])
+def test_segmented_pages_vs_oracle(ctx, bits, seg_bytes):
+    rng = np.random.default_rng(100 + bits + seg_bytes)
+    dt = np.int32 if bits == 32 else np.int64
+    cases = []
+    for n in (5000, 20000, 20001, 16385, 16513, 100_000):
+        for wmax in (0, 1, 5, 12, 16, 24, 31):
+            for block in (128, 256):
+                vals = _values(rng, n, wmax, dt)
+                stream = synth.delta_encode(vals, bits, block, 4)
+                for pull in sorted({n, n - 1, n + 3, n // 2, 129, 1}):
+                    cases.append(_case(bits, stream, pull))
+    _run(ctx, cases, bits, seg_bytes, seed=1)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_one_million_value_pages(ctx, bits):
+    """SURVEY's large-page shape (1 M values a page) under the segment length the library picks."""
+    rng = np.random.default_rng(7 + bits)
+    dt = np.int32 if bits == 32 else np.int64
+    cases = []
+    for wmax, block in ((16, 128), (9, 256), (30, 128)):
+        vals = _values(rng, 1_000_000, wmax, dt)
+        stream = synth.delta_encode(vals, bits, block, 4)
+        cases.append(_case(bits, stream, vals.size))
+        # cut inside a late segment: the first failing byte still decides count and status
+        for cut in (stream.size - 1, stream.size - 700, stream.size * 7 // 8 + 3, stream.size // 2):
+            c = Case(cases[-1].kind, stream[:cut].copy(), vals.size)
+            c.result_src_len = cut
+            cases.append(c)
+    try:
+        ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 2048)
+        ctx.set_option(K.OPT_SEGMENT_BYTES, 0)
+        run_cases(ctx, cases, seed=2)
+        for c in cases:
+            _check(c, bits)
+    finally:
+        ctx.set_option(K.OPT_SEGMENT_BYTES, 0)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_truncated_inside_every_segment(ctx, bits):
+    rng = np.random.default_rng(300 + bits)
+    dt = np.int32 if bits == 32 else np.int64
+    cases = []
+    for block in (128, 256):
+        vals = _values(rng, 9000, 11, dt)
+        stream = synth.delta_encode(vals, bits, block, 4)
+        cuts = sorted(set(rng.integers(0, stream.size, size=250).tolist()) |
+                      set(range(stream.size - 40, stream.size + 1)) |
+                      {k * 2048 + d for k in range(1, stream.size // 2048 + 1) for d in (-2, -1, 0, 1, 2, 7)
+                       if k * 2048 + d <= stream.size})
+        for cut in cuts:
+            c = Case(K.KIND_DELTA32 if bits == 32 else K.KIND_DELTA64, stream[:cut].copy(), vals.size)
+            c.result_src_len = cut
+            cases.append(c)
+    _run(ctx, cases, bits, 2048, seed=3)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_wrong_guesses_fall_back_to_the_chain(ctx, bits):
+    """Streams in which byte offsets that are not block headers look like block headers (constant
+    strides: blocks of a few small bytes), streams whose block headers the quick walk refuses
+    (minDelta of five varint bytes and more), damaged blocks and layouts that are not tiled."""
+    rng = np.random.default_rng(500 + bits)
+    dt = np.int32 if bits == 32 else np.int64
+    cases = []
+    n = 60000
+    # all deltas equal: every block is minDelta + four zero widths
+    for stride in (0, 5, -3, 1000):
+        vals = (np.arange(n, dtype=np.int64) * stride + 17).astype(dt)
+        for block in (128, 256):
+            cases.append(_case(bits, synth.delta_encode(vals, bits, block, 4), n))
+    # tiny widths: packed bytes are small numbers, many offsets pass as headers
+    for wmax in (1, 2, 3):
+        vals = _values(rng, 300_000, wmax, dt, base=0)
+        cases.append(_case(bits, synth.delta_encode(vals, bits, 128, 4), vals.size))
+    # minDelta needs 5 varint bytes (int64 only: |minDelta| >= 2^27 with 32-bit residuals)
+    big = 10**9 if bits == 64 else 2**28
+    vals = _values(rng, 50000, 10, dt, base=big if bits == 64 else 0)
+    if bits == 32:
+        with np.errstate(over="ignore"):
+            vals = (np.arange(50000, dtype=np.int64) * big + rng.integers(0, 1000, size=50000)).astype(np.int32)
+    cases.append(_case(bits, synth.delta_encode(vals, bits, 128, 4), vals.size))
+    # a width byte above 32 in the middle of the page, and garbage behind a good start
+    vals = _values(rng, 40000, 13, dt)
+    stream = synth.delta_encode(vals, bits, 128, 4)
+    for frac in (0.3, 0.6, 0.95):
+        s = stream.copy()
+        at = int(s.size * frac)
+        s[at: at + 600] = 0xC7
+        cases.append(_case(bits, s, vals.size))
+    s = stream.copy()
+    s[s.size // 2:] = rng.integers(0, 256, size=s.size - s.size // 2, dtype=np.uint8)
+    cases.append(_case(bits, s, vals.size))
+    # layouts the tiled decoders decline (segment 0 hands the page on)
+    for block, mb in ((128, 2), (512, 4), (256, 8)):
+        cases.append(_case(bits, synth.delta_encode(vals, bits, block, mb), vals.size))
+    _run(ctx, cases, bits, 2048, seed=4)
+    _run(ctx, cases, bits, 8192, seed=5)
+
+
+def test_large_and_small_pages_in_one_plan(ctx):
+    rng = np.random.default_rng(9)
+    cases = []
+    for i in range(40):
+        n = int(rng.choice([10, 300, 5000, 40000, 250_000]))
+        bits = 32 if i % 3 == 0 else 64
+        dt = np.int32 if bits == 32 else np.int64
+        vals = _values(rng, n, int(rng.integers(0, 25)), dt)
+        c = _case(bits, synth.delta_encode(vals, bits, 128 if i % 2 else 256, 4), n)
+        c.bits = bits
+        cases.append(c)
+    run_cases(ctx, cases, seed=6)
+    for c in cases:
+        _check(c, c.bits)
+
+
+def test_a_healthy_page_is_decoded_by_all_its_segments(ctx):
+    """On ordinary pages every guess is right: each segment is decoded by a wave of its own (all but
+    the few behind the page's last block).  A regression here would only show as lost speed."""
+    import torch
+    rng = np.random.default_rng(77)
+    dev = torch.device("cuda:0")
+    for bits, wmax, block in ((64, 16, 128), (64, 9, 256), (32, 12, 128), (64, 3, 128)):
+        dt = np.int32 if bits == 32 else np.int64
+        vals = _values(rng, 1_000_000, wmax, dt)
+        stream = synth.delta_encode(vals, bits, block, 4)
+        descs = np.zeros(1, dtype=K.DESC_DTYPE)
+        descs["kind"] = K.KIND_DELTA32 if bits == 32 else K.KIND_DELTA64
+        descs["src_len"], descs["n_values"] = stream.size, vals.size
+        t_src = torch.from_numpy(np.concatenate([stream, np.zeros(32, np.uint8)])).to(dev)
+        t_out = torch.zeros(vals.size, dtype=torch.int32 if bits == 32 else torch.int64, device=dev)
+        plan = ctx.plan(descs)
+        plan.run(t_src.data_ptr(), stream.size, t_out.data_ptr(), vals.size * (bits // 8))
+        res = plan.results()
+        segs = plan.segments()
+        plan.close()
+        assert res[0]["status"] == K.OK and res[0]["n_decoded"] == vals.size
+        assert np.array_equal(t_out.cpu().numpy(), vals)
+        assert segs.size == (stream.size + 8191) // 8192
+        apart = int((segs["decode"] != 0).sum())
+        assert apart >= segs.size - 2, (bits, wmax, block, apart, segs.size)
+        assert int((segs["decode"] == 2).sum()) == 1

@@ -170,13 +170,15 @@ def bench_nested(ctx, stream, pages, n):
     plan.close()
 
 
-def bench_delta(ctx, stream, pages, n, bits, width):
+def bench_delta(ctx, stream, pages, n, bits, width, label=""):
     rng = np.random.default_rng(3)
     dt = np.int64 if bits == 64 else np.int32
-    streams = []
+    streams, keep = [], {}
     for p in range(pages):
         steps = rng.integers(0, 1 << width, size=n - 1, dtype=np.int64) - 5
         v = np.concatenate([[p * 7], p * 7 + np.cumsum(steps)]).astype(dt)
+        if p in (0, pages // 2, pages - 1):
+            keep[p] = v
         streams.append(synth.delta_encode(v, bits))
     src, offs, lens = pack_pages(streams)
     descs = np.zeros(pages, dtype=capi.DESC_DTYPE)
@@ -191,7 +193,10 @@ def bench_delta(ctx, stream, pages, n, bits, width):
     t = timed(fn, stream)
     res = plan.results()
     assert (res["status"] == 0).all() and (res["n_decoded"] == n).all()
-    report("C2x delta%d width %d" % (bits, width), int(lens.sum()), pages * n * es, t,
+    got = t_out.view(torch.int64 if bits == 64 else torch.int32).view(pages, n)
+    for p, v in keep.items():
+        assert np.array_equal(got[p].cpu().numpy(), v), ("values differ", p)
+    report("C2x delta%d width %d%s" % (bits, width, label), int(lens.sum()), pages * n * es, t,
            {"pages": pages, "values_per_page": n})
     plan.close()
 
@@ -389,6 +394,15 @@ def main():
         bench_delta(ctx, stream, 100, 1_000_000, 64, 16)
         bench_delta(ctx, stream, 1000, 100_000, 64, 16)
         ctx.set_option(capi.OPT_DELTA_WAVE_MIN_PAGES, 1)
+    if want("c2seg"):    # large pages cut into segments (the default) against one wave per page
+        for seg in (2048, 0):
+            ctx.set_option(capi.OPT_SEGMENT_MAX_PAGES, seg)
+            lab = ", segmented" if seg else ", one wave per page"
+            bench_delta(ctx, stream, 1, 1_000_000, 64, 16, lab)
+            bench_delta(ctx, stream, 100, 1_000_000, 64, 16, lab)
+            bench_delta(ctx, stream, 1000, 100_000, 64, 16, lab)
+            bench_delta(ctx, stream, 100, 1_000_000, 32, 12, lab)
+        ctx.set_option(capi.OPT_SEGMENT_MAX_PAGES, 2048)
     if want("plain"):
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_PLAIN, 8, "P PLAIN int64")
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_PLAIN, 4, "P PLAIN int32")
