@@ -242,15 +242,22 @@ int pq_plan_results(pq_plan *plan, pq_page_result *results);
  * a page's segments in stream order; *n_segments = how many there are, at most `cap` are copied
  * (segs may be NULL with cap 0).  Waits for the stream. */
 typedef struct pq_segment_info {
-    uint32_t entry;   /* decode 1, 2: stream offset of the block header the segment starts at */
-    uint32_t exit;    /* where its walk of whole blocks reached the next segment; 0xffffffff: it did not */
-    uint32_t n_blocks;/* blocks walked */
-    uint32_t decode;  /* 0: decoded by a segment in front of it, serially; 1: by a wave of its own, up to
-                         the next such segment; 2: by a wave of its own, to the end of the page;
-                         3: the whole page by one wave (its segment 0) */
-    uint64_t value;   /* decode 1, 2: the value at position `position` */
-    uint32_t position;/* decode 1, 2: index in the page of the segment's first value */
-    uint32_t stop;    /* decode 1: stream offset of the block header it stops in front of */
+    uint32_t key;      /* where the segment's scan took its first block's four width bytes to be (stream
+                          offset; 0xffffffff: found none) */
+    uint32_t exit;     /* header of the next segment's first block as its walk of whole blocks reached it;
+                          0xffffffff: it did not */
+    uint32_t n_blocks; /* blocks walked */
+    uint32_t exit_key; /* width bytes of the header at `exit` */
+    uint64_t sum;      /* sum of the walked deltas (without the first block's minDelta, but in segment 0) */
+    uint32_t exit_min_delta;
+    uint32_t decode;   /* 0: decoded by a segment in front of it, serially; 1: by a wave of its own, up to
+                          the next such segment; 2: by a wave of its own, to the end of the page;
+                          3: the whole page by one wave (its segment 0) */
+    uint64_t value;    /* decode 1, 2: the value at position `position` */
+    uint32_t entry;    /* decode 1, 2: stream offset of the block header the segment starts at */
+    uint32_t position; /* decode 1, 2: index in the page of the segment's first value */
+    uint32_t stop;     /* decode 1: stream offset of the block header it stops in front of */
+    uint32_t reserved[3];
 } pq_segment_info;
 int pq_plan_segments(pq_plan *plan, pq_segment_info *segs, size_t cap, size_t *n_segments);
 void pq_plan_destroy(pq_plan *plan);

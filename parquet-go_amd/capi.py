@@ -479,8 +479,10 @@ class Plan:
             pass
 
 
-SEGMENT_DTYPE = np.dtype([("entry", "<u4"), ("exit", "<u4"), ("n_blocks", "<u4"), ("decode", "<u4"),
-                          ("value", "<u8"), ("position", "<u4"), ("stop", "<u4")])
+SEGMENT_DTYPE = np.dtype([("key", "<u4"), ("exit", "<u4"), ("n_blocks", "<u4"), ("exit_key", "<u4"), ("sum", "<u8"),
+                          ("exit_min_delta", "<u4"), ("decode", "<u4"), ("value", "<u8"), ("entry", "<u4"),
+                          ("position", "<u4"), ("stop", "<u4"), ("reserved", "<u4", (3,))])
+assert SEGMENT_DTYPE.itemsize == 64
 DICT_COPY_DTYPE = np.dtype([("src", "<u8"), ("dst", "<u8"), ("bytes", "<u8")])
 
 

@@ -73,17 +73,22 @@ struct SegPage {
 // One record per segment, written on the device.
 constexpr uint32_t kSegSkip = 0, kSegPart = 1, kSegTail = 2, kSegWhole = 3;
 struct SegRec {
-    uint32_t entry;  // scan: guessed stream offset of the first block's width bytes (0xffffffff: none);
-                     // linked: stream offset of that block's header
-    uint32_t exit;   // header of the first block of the next segment, reached by walking whole blocks
-    uint32_t nblk;   // blocks walked
-    uint32_t flags;  // kSeg*: what the decode does with the segment
-    uint64_t sum;    // scan: sum of the walked blocks' deltas without the first block's minDelta;
-                     // linked: the value at position p0
-    uint32_t p0;     // scan: stream offset of the width bytes of the header at `exit`;
-                     // linked: position of the segment's first value
-    uint32_t stop;   // scan: minDelta of the header at `exit`; linked, kSegPart: stream offset to stop in front of
+    // written by the scan (a guess until the link pass has proven it)
+    uint32_t key;      // stream offset of the first block's width bytes (0xffffffff: none found)
+    uint32_t exit;     // header of the first block of the next segment, reached by walking whole blocks
+    uint32_t nblk;     // blocks walked
+    uint32_t exit_key; // stream offset of the width bytes of the header at `exit`
+    uint64_t sum;      // sum of the walked blocks' deltas, without the first block's minDelta (segment 0: with it)
+    uint32_t exit_md;  // minDelta of the header at `exit`
+    // written by the link pass
+    uint32_t flags;    // kSeg*: what the decode does with the segment
+    uint64_t value;    // the value at position p0
+    uint32_t entry;    // stream offset of the first block's header
+    uint32_t p0;       // position of the segment's first value
+    uint32_t stop;     // kSegPart: stream offset to stop in front of
+    uint32_t pad[3];
 };
+static_assert(sizeof(SegRec) == 64, "segment records are 64 bytes");
 // d_pages / d_owner (segment -> index into d_pages) / d_recs: n_pages, n_segs, n_segs entries.
 hipError_t launch_seg_delta(hipStream_t s, int bits, const pq_page_desc *d_descs, SegPage *d_pages, uint32_t n_pages,
                             const uint32_t *d_owner, uint32_t n_segs, SegRec *d_recs, PageBuffers buf,

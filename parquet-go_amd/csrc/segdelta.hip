@@ -23,7 +23,10 @@
 //                         width bytes are where segment s + 1 guessed them (and that block still
 //                         has a value the caller wants).  Proven segments get their true header,
 //                         their first value's position and the value itself (prefix sums of block
-//                         counts and delta sums).
+//                         counts and delta sums).  Where a guess was wrong the wave walks that
+//                         segment again itself, from where the chain says it starts, and goes on
+//                         (a few times per page; beyond that the rest of the page is left to the
+//                         last proven segment).
 //   4. seg_decode_kernel  one wave per proven segment decodes up to the next proven segment with
 //                         the page decoder's own tile loop; the last proven one runs to the end of
 //                         the page through the checked path, so the tail rules, the status and the
@@ -86,6 +89,18 @@ struct SegCand {
     uint32_t next;  // window offset of the header behind this block
 };
 
+// What a scan leaves in a segment's record (the link fields are written by seg_link_kernel).
+__device__ __forceinline__ void seg_store(SegRec *rec, uint32_t key, uint32_t exit_off, uint32_t nblk, uint32_t exit_key,
+                                          uint64_t sum, uint32_t exit_md)
+{
+    rec->key = key;
+    rec->exit = exit_off;
+    rec->nblk = nblk;
+    rec->exit_key = exit_key;
+    rec->sum = sum;
+    rec->exit_md = exit_md;
+}
+
 template <uint32_t LG>
 __device__ __forceinline__ SegCand seg_parse(const uint32_t *lds, uint32_t wo, uint32_t lim)
 {
@@ -112,14 +127,15 @@ __device__ __forceinline__ SegCand seg_parse(const uint32_t *lds, uint32_t wo, u
     return c;
 }
 
-template <typename UT, uint32_t LG>
+// forced != kSegNone: no guess, the first block's width bytes are known to be at `forced`.
+template <uint32_t LG>
 __device__ __forceinline__ void seg_scan(uint32_t *lds, const uint8_t *S, int64_t len, uint32_t s, uint32_t seg_bytes,
-                                         uint32_t pos0, SegRec *rec, int lane)
+                                         uint32_t pos0, SegRec *rec, int lane, uint32_t forced = kSegNone)
 {
     constexpr uint32_t kBlockMax = LG == 5u ? 544u : 1040u;  // >= the longest block, a multiple of 16
     const int64_t lo = (int64_t)s * seg_bytes, hi = lo + seg_bytes;
     WavePrefetch pf;
-    int64_t c0 = chunk_base(S, s == 0u ? 0 : lo - 1);
+    int64_t c0 = chunk_base(S, s == 0u ? 0 : (forced != kSegNone ? (int64_t)forced - 1 : lo - 1));
     wave_fetch(pf, S, c0, len, lane);
     wave_commit(lds, pf, lane);
     wave_sync();
@@ -131,6 +147,8 @@ __device__ __forceinline__ void seg_scan(uint32_t *lds, const uint8_t *S, int64_
     uint32_t key = kSegNone;
     if (s == 0u) {
         key = pos0;  // not a guess, and not used: the walk starts at the header itself
+    } else if (forced != kSegNone) {
+        key = forced;
     } else {
         // A segment owns the blocks whose width bytes start in it.  The byte in front of those of
         // its first block (the end of the varint) is at lo - 1 or behind.
@@ -139,7 +157,11 @@ __device__ __forceinline__ void seg_scan(uint32_t *lds, const uint8_t *S, int64_
             const uint32_t wo = base + r + (uint32_t)lane;
             SegCand a = seg_parse<LG>(lds, wo, lim0);
             bool pass = a.ok;
-            if (pass && a.next < lim0) pass = seg_parse<LG>(lds, a.next, lim0).ok;
+            if (pass && a.next < lim0) {  // and the two headers behind it, as far as the window shows them
+                const SegCand b = seg_parse<LG>(lds, a.next, lim0);
+                pass = b.ok;
+                if (pass && b.next + 16u <= (uint32_t)kDwChunk && b.next < lim0) pass = seg_parse<LG>(lds, b.next, lim0).ok;
+            }
             const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
             if (m != 0ull) {
                 const uint32_t first = (uint32_t)__builtin_ctzll(m);
@@ -150,10 +172,7 @@ __device__ __forceinline__ void seg_scan(uint32_t *lds, const uint8_t *S, int64_
     }
     key = uni(key);
     if (key == kSegNone) {
-        if (lane == 0) {
-            SegRec out{kSegNone, kSegNone, 0u, 0u, 0ull, kSegNone, 0u};
-            *rec = out;
-        }
+        if (lane == 0) seg_store(rec, kSegNone, kSegNone, 0u, kSegNone, 0ull, 0u);
         return;
     }
 
@@ -215,13 +234,9 @@ __device__ __forceinline__ void seg_scan(uint32_t *lds, const uint8_t *S, int64_
         o -= (uint32_t)kDwStride;
     }
     const uint64_t total = wave_last_u64(wave_scan_u64(acc)) + msum;
-    if (lane == 0) {
-        SegRec out{key, exit_off, nblk, 0u, total, exit_key, exit_md};
-        *rec = out;
-    }
+    if (lane == 0) seg_store(rec, key, exit_off, nblk, exit_key, total, exit_md);
 }
 
-template <typename UT>
 __global__ __launch_bounds__(kWG) void seg_scan_kernel(const pq_page_desc *__restrict__ descs,
                                                        const SegPage *__restrict__ pages,
                                                        const uint32_t *__restrict__ owner, uint32_t n_segs,
@@ -235,26 +250,26 @@ __global__ __launch_bounds__(kWG) void seg_scan_kernel(const pq_page_desc *__res
     const SegPage pg = pages[owner[g]];
     const uint32_t s = g - pg.seg_first;
     if (pg.whole) {
-        if (lane == 0) {
-            SegRec out{kSegNone, kSegNone, 0u, 0u, 0ull, 0u, kSegNone};
-            recs[g] = out;
-        }
+        if (lane == 0) seg_store(recs + g, kSegNone, kSegNone, 0u, kSegNone, 0ull, 0u);
         return;
     }
     const pq_page_desc d = descs[pg.desc];
     const uint8_t *S = buf.src + d.src_off;
     if (pg.lg == 5u)
-        seg_scan<UT, 5>(window[wave], S, (int64_t)d.src_len, s, pg.seg_bytes, pg.pos0, recs + g, lane);
+        seg_scan<5>(window[wave], S, (int64_t)d.src_len, s, pg.seg_bytes, pg.pos0, recs + g, lane);
     else
-        seg_scan<UT, 6>(window[wave], S, (int64_t)d.src_len, s, pg.seg_bytes, pg.pos0, recs + g, lane);
+        seg_scan<6>(window[wave], S, (int64_t)d.src_len, s, pg.seg_bytes, pg.pos0, recs + g, lane);
 }
 
 // ---- 3. proofs and prefix sums -----------------------------------------------------------------
 
+constexpr uint32_t kSegRepairs = 8;  // wrong guesses per page the link pass walks again itself
+
 __global__ __launch_bounds__(kWG) void seg_link_kernel(const pq_page_desc *__restrict__ descs,
                                                        const SegPage *__restrict__ pages, uint32_t n_pages,
-                                                       SegRec *__restrict__ recs)
+                                                       SegRec *__restrict__ recs, PageBuffers buf)
 {
+    __shared__ __attribute__((aligned(16))) uint32_t window[kWG / kWave][kDwChunk / 4 + 4];
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t pi = blockIdx.x * (kWG / kWave) + wave;
@@ -267,31 +282,39 @@ __global__ __launch_bounds__(kWG) void seg_link_kernel(const pq_page_desc *__res
         return;
     }
     const pq_page_desc d = descs[pg.desc];
+    const uint8_t *S = buf.src + d.src_off;
     const uint32_t need = min(d.n_values, pg.total);
     const uint64_t V = 128ull << (pg.lg - 5u);
     // K = number of proven segments (a prefix of the page's segments, at least segment 0)
-    uint32_t K = ns;
+    uint32_t K = ns, repairs = 0;
     uint64_t blocks_before = 0, carry = pg.first;
     uint32_t prev_exit = kSegNone, prev_key = kSegNone, prev_md = 0;
-    for (uint32_t base = 0; base < ns; base += kWave) {
+    uint32_t base = 0;
+    while (base < ns) {
         const uint32_t s = base + lane;
         const bool valid = s < ns;
-        // as seg_scan left it: entry = guessed place of the width bytes, p0 = place of the width
-        // bytes of the header at `exit`, stop = that header's minDelta
-        SegRec r{kSegNone, kSegNone, 0u, 0u, 0ull, kSegNone, 0u};
-        if (valid) r = R[s];
-        uint32_t b_exit = (uint32_t)__shfl_up((int)r.exit, 1);
-        uint32_t b_key = (uint32_t)__shfl_up((int)r.p0, 1);
-        uint32_t b_md = (uint32_t)__shfl_up((int)r.stop, 1);
+        uint32_t key = kSegNone, exit_off = kSegNone, nb = 0, exit_key = kSegNone, exit_md = 0;
+        uint64_t rsum = 0;
+        if (valid) {
+            const SegRec &r = R[s];
+            key = r.key;
+            exit_off = r.exit;
+            nb = r.nblk;
+            exit_key = r.exit_key;
+            exit_md = r.exit_md;
+            rsum = r.sum;
+        }
+        uint32_t b_exit = (uint32_t)__shfl_up((int)exit_off, 1);
+        uint32_t b_key = (uint32_t)__shfl_up((int)exit_key, 1);
+        uint32_t b_md = (uint32_t)__shfl_up((int)exit_md, 1);
         if (lane == 0) {
             b_exit = prev_exit;
             b_key = prev_key;
             b_md = prev_md;
         }
-        const bool link = s == 0u || (r.entry != kSegNone && b_key != kSegNone && b_key == r.entry);
+        const bool link = s == 0u || (key != kSegNone && b_key != kSegNone && b_key == key);
         // the first block's minDelta, which the guess could not know
-        const uint64_t sum = valid ? r.sum + (s == 0u ? 0ull : V * (uint64_t)(int64_t)(int32_t)b_md) : 0ull;
-        const uint32_t nb = valid ? r.nblk : 0u;
+        const uint64_t sum = valid ? rsum + (s == 0u ? 0ull : V * (uint64_t)(int64_t)(int32_t)b_md) : 0ull;
         const uint32_t incl_b = wave_scan_u32(nb);
         const uint64_t incl_s = wave_scan_u64(sum);
         const uint64_t b_s = blocks_before + incl_b - nb;
@@ -299,10 +322,26 @@ __global__ __launch_bounds__(kWG) void seg_link_kernel(const pq_page_desc *__res
         const bool wanted = V * b_s < (uint64_t)need;  // the segment's first value is one the caller pulls
         const uint64_t bad = __builtin_amdgcn_ballot_w64(valid && !(link && wanted));
         const uint32_t first_bad = bad != 0ull ? (uint32_t)__builtin_ctzll(bad) : (uint32_t)kWave;
+        if (bad != 0ull) {
+            // a wrong guess (the chain in front says where the segment starts, it still has values
+            // the caller wants, and the guess was elsewhere): walk the segment again from there
+            const uint32_t want_key = (uint32_t)__builtin_amdgcn_readlane((int)b_key, (int)first_bad);
+            const bool still = __builtin_amdgcn_readlane((int)(wanted ? 1u : 0u), (int)first_bad) != 0;
+            if (still && want_key != kSegNone && repairs < kSegRepairs) {
+                repairs += 1u;
+                const uint32_t sk = base + first_bad;
+                if (pg.lg == 5u)
+                    seg_scan<5>(window[wave], S, (int64_t)d.src_len, sk, pg.seg_bytes, pg.pos0, R + sk, (int)lane, want_key);
+                else
+                    seg_scan<6>(window[wave], S, (int64_t)d.src_len, sk, pg.seg_bytes, pg.pos0, R + sk, (int)lane, want_key);
+                __threadfence();  // lane 0 wrote the record; every lane reads it next
+                continue;         // the same 64 segments once more
+            }
+        }
         if (valid && lane < first_bad) {
             R[s].entry = s == 0u ? pg.pos0 : b_exit;  // the header itself, as the chain reached it
             R[s].p0 = (uint32_t)(V * b_s);
-            R[s].sum = carry_s;  // from here on: the value at position p0
+            R[s].value = carry_s;
         }
         if (bad != 0ull) {
             K = base + first_bad;
@@ -310,9 +349,10 @@ __global__ __launch_bounds__(kWG) void seg_link_kernel(const pq_page_desc *__res
         }
         blocks_before += wave_last_u32(incl_b);
         carry += wave_last_u64(incl_s);
-        prev_exit = (uint32_t)__builtin_amdgcn_readlane((int)r.exit, 63);
-        prev_key = (uint32_t)__builtin_amdgcn_readlane((int)r.p0, 63);
-        prev_md = (uint32_t)__builtin_amdgcn_readlane((int)r.stop, 63);
+        prev_exit = (uint32_t)__builtin_amdgcn_readlane((int)exit_off, 63);
+        prev_key = (uint32_t)__builtin_amdgcn_readlane((int)exit_key, 63);
+        prev_md = (uint32_t)__builtin_amdgcn_readlane((int)exit_md, 63);
+        base += kWave;
     }
     K = uni(K);
     for (uint32_t s = lane; s < ns; s += kWave) {
@@ -360,7 +400,7 @@ __global__ __launch_bounds__(kWG) void seg_decode_kernel(const pq_page_desc *__r
         const int64_t entry = (int64_t)uni(rec.entry);
         const int64_t stop = flags == kSegPart ? (int64_t)uni(rec.stop) : -1;
         const uint32_t p0 = uni(rec.p0);
-        const uint64_t first = ((uint64_t)uni((uint32_t)(rec.sum >> 32)) << 32) | uni((uint32_t)rec.sum);
+        const uint64_t first = ((uint64_t)uni((uint32_t)(rec.value >> 32)) << 32) | uni((uint32_t)rec.value);
         WavePrefetch pf;
         const int64_t c0 = chunk_base(S, entry);
         wave_fetch(pf, S, c0, len, lane);
@@ -395,14 +435,12 @@ hipError_t launch_seg_delta(hipStream_t s, int bits, const pq_page_desc *d_descs
     if (n_pages == 0 || n_segs == 0) return hipSuccess;
     const uint32_t per = kWG / kWave;
     const dim3 gp((n_pages + kWave - 1) / kWave), gs((n_segs + per - 1) / per), gl((n_pages + per - 1) / per);
-    if (bits == 64) {
+    if (bits == 64)
         hipLaunchKernelGGL(seg_header_kernel<uint64_t>, gp, dim3(kWave), 0, s, d_descs, d_pages, n_pages, buf);
-        hipLaunchKernelGGL(seg_scan_kernel<uint64_t>, gs, dim3(kWG), 0, s, d_descs, d_pages, d_owner, n_segs, d_recs, buf);
-    } else {
+    else
         hipLaunchKernelGGL(seg_header_kernel<uint32_t>, gp, dim3(kWave), 0, s, d_descs, d_pages, n_pages, buf);
-        hipLaunchKernelGGL(seg_scan_kernel<uint32_t>, gs, dim3(kWG), 0, s, d_descs, d_pages, d_owner, n_segs, d_recs, buf);
-    }
-    hipLaunchKernelGGL(seg_link_kernel, gl, dim3(kWG), 0, s, d_descs, d_pages, n_pages, d_recs);
+    hipLaunchKernelGGL(seg_scan_kernel, gs, dim3(kWG), 0, s, d_descs, d_pages, d_owner, n_segs, d_recs, buf);
+    hipLaunchKernelGGL(seg_link_kernel, gl, dim3(kWG), 0, s, d_descs, d_pages, n_pages, d_recs, buf);
     if (bits == 64)
         hipLaunchKernelGGL(seg_decode_kernel<uint64_t>, gs, dim3(kWG), 0, s, d_descs, d_pages, d_owner, n_segs, d_recs,
                            buf, d_results, d_flag, epoch);

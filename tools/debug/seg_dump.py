@@ -70,8 +70,8 @@ def main():
             k = int(skipped[0])
             hdr, keys = true_headers(s)
             j = int(np.searchsorted(keys, k * L))
-            print("  first serial segment", k, "lo", k * L, dict(zip(segs.dtype.names, [int(x) for x in segs[k]])))
-            print("  segment in front    ", dict(zip(segs.dtype.names, [int(x) for x in segs[k - 1]])))
+            print("  first serial segment", k, "lo", k * L, {nm: int(segs[k][nm]) for nm in segs.dtype.names if nm != "reserved"})
+            print("  segment in front    ", {nm: int(segs[k - 1][nm]) for nm in segs.dtype.names if nm != "reserved"})
             print("  true headers around ", hdr[j - 1:j + 2].tolist(), "width bytes at", keys[j - 1:j + 2].tolist())
             a = int(hdr[j]) - 12
             print("  bytes from", a, ":", s[a:a + 32].tolist())
