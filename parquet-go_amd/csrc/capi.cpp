@@ -473,8 +473,8 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
         for (uint32_t i : g) bytes += descs[i].src_len;
         uint64_t L = ctx->seg_bytes;
         if (L == 0) {
-            L = 8192;  // about 8192 segments in flight, between 8 and 64 KiB each
-            while (L < 65536 && L * 8192 < bytes) L *= 2;
+            L = 8192;  // up to 16384 segments (two waves to each of the machine's wave slots), 8 to 64 KiB each
+            while (L < 65536 && L * 16384 < bytes) L *= 2;
         }
         auto cut = [&](uint32_t i) {
             const pq_page_desc &d = descs[i];

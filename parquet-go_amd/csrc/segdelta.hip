@@ -184,56 +184,118 @@ __device__ __forceinline__ void seg_scan(uint32_t *lds, const uint8_t *S, int64_
     ln.sh8 = ((2u * (uint32_t)lane) >> LG) * 8u;
     ln.k2 = (2u * (uint32_t)lane) & ((1u << LG) - 1u);
     WaveBlock blk{0, 0, 0, 0, 0, 0};
-    uint64_t acc = 0;      // per lane: the deltas it unpacked
-    uint64_t msum = 0;     // minDelta x 128 per tile, the first block's tiles left out (not in segment 0)
+    uint64_t acc = 0;      // per lane: the deltas it unpacked, minDelta included except in the first
+                           // block's tiles (segment 0: there too)
     uint32_t nblk = 0, exit_off = kSegNone, exit_key = kSegNone, exit_md = 0;
     uint32_t o = (uint32_t)((s == 0u ? (int64_t)pos0 : (int64_t)key - 1) - c0), p0 = 0;  // segment 0 knows its header
     bool done = false;
-    while (true) {
-        const int64_t c1 = c0 + kDwStride;
-        const bool tail = c0 + kDwChunk >= len;
-        if (!tail) wave_fetch(pf, S, c1, len, lane);
-        const int64_t left = len - c0;
-        const uint32_t lim = left > (int64_t)kDwChunk ? (uint32_t)kDwChunk : (left < 0 ? 0u : (uint32_t)left);
-        while (tail || o + (uint32_t)kDwBlockMax <= (uint32_t)kDwChunk) {
-            const bool at_header = LG == 5u || blk.half == 0u;
-            const int64_t header = c0 + (int64_t)o;
-            WaveTile t = wave_tile_none();
-            if (!wave_walk_fast<LG>(t, lds, o, lim, p0, 0xffffffffu, blk)) {
-                done = true;  // not a whole, plain block: the walk (and the chain of proofs) ends here
-                break;
+    int32_t hi_rel = (int32_t)(hi - c0);  // `hi` as a window offset
+    if constexpr (LG == 5u) {
+        // Blocks of 128: the header walk of wave_walk_fast with nothing the sum does not need, and
+        // one way out of the inner loop (what ended it is worked out behind it, once).
+        uint32_t md_mask = s == 0u ? 0xffffffffu : 0u;  // the first block's minDelta is left out
+        while (true) {
+            const int64_t c1 = c0 + kDwStride;
+            const bool tail = c0 + kDwChunk >= len;
+            if (!tail) wave_fetch(pf, S, c1, len, lane);
+            const int64_t left = len - c0;
+            const uint32_t lim = left > (int64_t)kDwChunk ? (uint32_t)kDwChunk : (left < 0 ? 0u : (uint32_t)left);
+            const uint32_t o_max = tail ? 0x7fffffffu : (uint32_t)(kDwChunk - kDwBlockMax);
+            uint32_t hdr_lo = 0, vl = 0, bad = 0;
+            while (o <= o_max) {
+                const uint32_t k = o >> 2, sh = (o & 3u) * 8u;
+                const uint32_t d0 = uni(lds[k]), d1 = uni(lds[k + 1]), d2 = uni(lds[k + 2]);
+                hdr_lo = (uint32_t)(((((uint64_t)d1) << 32) | d0) >> sh);
+                const uint32_t mid = (uint32_t)(((((uint64_t)d2) << 32) | d1) >> sh);
+                const uint32_t stop = ~hdr_lo & 0x80808080u;
+                vl = ((uint32_t)__builtin_ctz(stop | 0x80000000u) + 1u) >> 3;  // 1..4 (4 also when there is no end)
+                const uint32_t widths = (uint32_t)(((((uint64_t)mid) << 32) | hdr_lo) >> (8u * vl));
+                const uint32_t data = o + vl + 4u;
+                const uint32_t next = data + 4u * ((widths * 0x01010101u) >> 24);
+                // a minDelta of five bytes or more, a width above 32, a block that is not all there
+                bad = (stop == 0u ? 1u : 0u) | (((((widths & 0x7f7f7f7fu) + 0x5f5f5f5fu) | widths) & 0x80808080u) != 0u ? 1u : 0u) |
+                      (next > lim ? 1u : 0u);
+                if (bad != 0u || (int32_t)(o + vl) >= hi_rel) break;
+                const uint32_t w = __builtin_amdgcn_ubfe(widths, ln.sh8, 8u);
+                const uint32_t pre = __builtin_amdgcn_ubfe(widths * 0x01010100u, ln.sh8, 8u);
+                const uint32_t bit = data * 8u + (pre << 5) + ln.k2 * w;
+                const uint32_t i = bit >> 5, sft = bit & 31u;
+                const uint32_t e0 = lds[i], e1 = lds[i + 1], e2 = lds[i + 2];
+                const uint32_t l32 = __builtin_amdgcn_alignbit(e1, e0, sft);
+                const uint32_t h32 = __builtin_amdgcn_alignbit(e2, e1, sft);
+                const uint32_t m = (uint32_t)(1ull << w) - 1u;
+                const uint32_t ua = l32 & m;
+                const uint32_t ub = (uint32_t)((((uint64_t)h32 << 32) | l32) >> w) & m;
+                // minDelta twice per lane (its two values), expanded on the vector unit like the decode does
+                const int32_t md = wave_expand_min_delta(hdr_lo, vl) & (int32_t)md_mask;
+                acc += (uint64_t)ua + (uint64_t)ub + (uint64_t)(2ll * (int64_t)md);
+                md_mask = 0xffffffffu;
+                nblk += 1u;
+                o = next;
             }
-            if (at_header && header + (int64_t)t.vl >= hi) {
-                // the next segment's first block, reached along the chain: its header, where its
-                // width bytes are, and its minDelta
-                exit_off = (uint32_t)header;
-                exit_key = exit_off + t.vl;
-                exit_md = (uint32_t)(int32_t)wave_raw_min_delta(t.hdr_lo, t.vl);
-                done = true;
-                break;
+            if (o <= o_max) {  // left by the break
+                if (bad == 0u) {
+                    // the next segment's first block, reached along the chain: its header, where its
+                    // width bytes are, and its minDelta
+                    exit_off = (uint32_t)(c0 + (int64_t)o);
+                    exit_key = exit_off + vl;
+                    exit_md = (uint32_t)(int32_t)wave_raw_min_delta(hdr_lo, vl);
+                }
+                break;  // else: not a whole, plain block; the walk (and the chain of proofs) ends here
             }
-            const uint32_t w = __builtin_amdgcn_ubfe(t.widths, ln.sh8, 8u);
-            const uint32_t pre = __builtin_amdgcn_ubfe(t.prefix, ln.sh8, 8u);
-            const uint32_t bit = t.bitbase + (pre << LG) + ln.k2 * w;
-            const uint32_t i = bit >> 5, sft = bit & 31u;
-            const uint32_t d0 = lds[i], d1 = lds[i + 1], d2 = lds[i + 2];
-            const uint32_t l32 = __builtin_amdgcn_alignbit(d1, d0, sft);
-            const uint32_t h32 = __builtin_amdgcn_alignbit(d2, d1, sft);
-            const uint32_t m = (uint32_t)(1ull << w) - 1u;
-            const uint32_t ua = l32 & m;
-            const uint32_t ub = (uint32_t)((((uint64_t)h32 << 32) | l32) >> w) & m;
-            acc += (uint64_t)ua + (uint64_t)ub;
-            if (nblk != 0u || s == 0u) msum += (uint64_t)(128ll * wave_raw_min_delta(t.hdr_lo, t.vl));
-            if (LG == 5u || blk.half == 0u) nblk += 1u;
+            if (tail) break;
+            wave_sync();
+            wave_commit(lds, pf, lane);
+            wave_sync();
+            c0 = c1;
+            o -= (uint32_t)kDwStride;
+            hi_rel -= kDwStride;
         }
-        if (done || tail) break;
-        wave_sync();
-        wave_commit(lds, pf, lane);
-        wave_sync();
-        c0 = c1;
-        o -= (uint32_t)kDwStride;
+    } else {
+        while (true) {
+            const int64_t c1 = c0 + kDwStride;
+            const bool tail = c0 + kDwChunk >= len;
+            if (!tail) wave_fetch(pf, S, c1, len, lane);
+            const int64_t left = len - c0;
+            const uint32_t lim = left > (int64_t)kDwChunk ? (uint32_t)kDwChunk : (left < 0 ? 0u : (uint32_t)left);
+            while (tail || o + (uint32_t)kDwBlockMax <= (uint32_t)kDwChunk) {
+                const bool header = blk.half == 0u;
+                const int64_t at = c0 + (int64_t)o;
+                WaveTile t = wave_tile_none();
+                if (!wave_walk_fast<LG>(t, lds, o, lim, p0, 0xffffffffu, blk)) {
+                    done = true;  // not a whole, plain block: the walk (and the chain of proofs) ends here
+                    break;
+                }
+                if (header && at + (int64_t)t.vl >= hi) {
+                    exit_off = (uint32_t)at;
+                    exit_key = exit_off + t.vl;
+                    exit_md = (uint32_t)(int32_t)wave_raw_min_delta(t.hdr_lo, t.vl);
+                    done = true;
+                    break;
+                }
+                const uint32_t w = __builtin_amdgcn_ubfe(t.widths, ln.sh8, 8u);
+                const uint32_t pre = __builtin_amdgcn_ubfe(t.prefix, ln.sh8, 8u);
+                const uint32_t bit = t.bitbase + (pre << LG) + ln.k2 * w;
+                const uint32_t i = bit >> 5, sft = bit & 31u;
+                const uint32_t e0 = lds[i], e1 = lds[i + 1], e2 = lds[i + 2];
+                const uint32_t l32 = __builtin_amdgcn_alignbit(e1, e0, sft);
+                const uint32_t h32 = __builtin_amdgcn_alignbit(e2, e1, sft);
+                const uint32_t m = (uint32_t)(1ull << w) - 1u;
+                const uint32_t ua = l32 & m;
+                const uint32_t ub = (uint32_t)((((uint64_t)h32 << 32) | l32) >> w) & m;
+                const int64_t md2 = (nblk != 0u || s == 0u) ? 2ll * (int64_t)wave_expand_min_delta(t.hdr_lo, t.vl) : 0ll;
+                acc += (uint64_t)ua + (uint64_t)ub + (uint64_t)md2;
+                if (blk.half == 0u) nblk += 1u;
+            }
+            if (done || tail) break;
+            wave_sync();
+            wave_commit(lds, pf, lane);
+            wave_sync();
+            c0 = c1;
+            o -= (uint32_t)kDwStride;
+        }
     }
-    const uint64_t total = wave_last_u64(wave_scan_u64(acc)) + msum;
+    const uint64_t total = wave_last_u64(wave_scan_u64(acc));
     if (lane == 0) seg_store(rec, key, exit_off, nblk, exit_key, total, exit_md);
 }
 
