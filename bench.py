@@ -138,18 +138,42 @@ def cpu_baseline(src, offs, lens, n, seconds=10.0):
                 all_cores_value=round(multi, 4), all_cores=cores)
 
 
-def measured_traffic(args, in_bytes, out_bytes):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter
-    passes (profiles/r01/traffic.json; the counters cannot be read from inside this
-    process).  Only valid for the workload they were collected on."""
-    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+def library_sha256():
+    import hashlib
+
+    from parquet_go_amd import capi
+    h = hashlib.sha256()
+    with open(capi.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def measured_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 counter passes
+    (profiles/r*/traffic.json; the counters cannot be read from inside this process).  The file
+    names the workload and the library build (sha256 of libpqdecode.so) it was collected on: any
+    other workload or build gets null, so the figure cannot go stale silently.
+    -> (bytes or None, dict describing where the figure comes from)"""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))
+    if not paths:
+        return None, {"traffic_source": None}
+    path = paths[-1]
+    src = {"traffic_source": os.path.relpath(path, ROOT)}
     try:
         t = json.load(open(path))
     except (OSError, ValueError):
-        return None
+        return None, src
+    src["traffic_library_sha256"] = t.get("library_sha256")
     if (t.get("pages"), t.get("values_per_page"), t.get("width")) != (args.pages, args.values_per_page, args.width):
-        return None
-    return t.get("hbm_bytes_per_launch")
+        src["traffic_note"] = "collected on another workload"
+        return None, src
+    if t.get("library_sha256") != library_sha256():
+        src["traffic_note"] = "collected on another build of libpqdecode.so"
+        return None, src
+    return t.get("hbm_bytes_per_launch"), src
 
 
 def main():
@@ -279,6 +303,7 @@ def main():
     e2e = time.perf_counter() - t1
 
     if rank == 0:
+        traffic, traffic_src = measured_traffic(args)
         value = world * out_bytes * args.steps / elapsed / 1e9
         line = {
             "metric": "device-resident decode GB/s (output) for hybrid/bitpack/delta pages, 1-8 GPU",
@@ -311,8 +336,9 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": measured_traffic(args, in_bytes, out_bytes),
+                "traffic": traffic,
                 "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, see profiles/)",
+                **traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(k_avg_s * 1e3, 4),
             },

@@ -15,6 +15,16 @@
  *   plain names        host pointers; the call stages H2D, decodes, copies
  *                      D2H and synchronises before returning.
  *
+ * Source buffers: the kernels read encoded bytes in whole, 16-byte aligned lines.  A unit that
+ * occupies [p, p + len) of a source buffer makes them read every aligned 16-byte line that
+ * intersects that range, i.e. up to 15 bytes in front of p and up to 15 bytes behind p + len (never
+ * a line that holds none of its bytes; what is read outside the unit never reaches an output).
+ * Device source buffers (d_src of pq_plan_run, pq_bitunpack*_dev, pq_walk_chunks_dev) must therefore
+ * be readable from the 16-byte boundary at or below their first byte to the one at or above their
+ * last: any hipMalloc'ed buffer is (its start is aligned and its size is rounded up), a pointer
+ * into the middle of one is as long as the allocation covers those lines.  The host-pointer entry
+ * points stage into buffers of their own and ask nothing of the caller's memory.
+ *
  * Threading: a pq_ctx (and the plans made from it) may be used by one thread at
  * a time; create one context per calling thread / goroutine-locked OS thread.
  */

@@ -49,7 +49,9 @@ def _closed_form(t_src, w, n_values, bits, torch):
     return out
 
 
-@pytest.mark.parametrize("bits,w", [(32, 1), (32, 12), (32, 31), (32, 32), (64, 33), (64, 47), (64, 64)])
+# every residue of the width mod 8 in both tables (9..16, 33..40), the ends of both, and a few more
+@pytest.mark.parametrize("bits,w", [(32, w) for w in (1, 9, 10, 11, 12, 13, 14, 15, 16, 31, 32)] +
+                         [(64, w) for w in (7, 33, 34, 35, 36, 37, 38, 39, 40, 47, 57, 64)])
 def test_bitunpack_one_gib_encoded(ctx, bits, w):
     import torch
     dev = torch.device("cuda:0")

@@ -112,17 +112,19 @@ def bench_dict(ctx, stream, pages, n, run_heavy, label):
     plan.close()
 
 
-def bench_bitunpack(ctx, stream, bits, widths, enc_bytes):
+def bench_bitunpack(ctx, stream, bits, widths, enc_bytes, out_cap=2 << 30):
     rng = np.random.default_rng(4)
     src = rng.integers(0, 256, size=enc_bytes + 64, dtype=np.uint8)
     t_src = torch.from_numpy(src).to(DEV)
     es = bits // 8
     for w in widths:
-        ng = min(enc_bytes // w, (2 << 30) // (8 * es))   # cap the output at 2 GiB
+        ng = min(enc_bytes // w, out_cap // (8 * es))     # cap the output
         t_out = torch.empty(ng * 8, dtype=torch.int32 if bits == 32 else torch.int64, device=DEV)
         fn = lambda: ctx.bitunpack_dev(t_src.data_ptr(), ng * w, w, ng, t_out.data_ptr(), bits)
         t = timed(fn, stream, steps=6, warmup=1)
-        report("C3 bitunpack%d w=%d" % (bits, w), ng * w, ng * 8 * es, t, {"groups": ng})
+        report("C3 bitunpack%d w=%d" % (bits, w), ng * w, ng * 8 * es, t,
+               {"groups": ng, "bits": bits, "width": w, "encoded_bytes": ng * w, "decoded_bytes": ng * 8 * es,
+                "output_capped": ng * w < enc_bytes - w})
         del t_out
 
 
@@ -381,6 +383,9 @@ def main():
     if want("c3"):
         bench_bitunpack(ctx, stream, 32, [1, 4, 8, 12, 16, 24, 32], 256 << 20)
         bench_bitunpack(ctx, stream, 64, [8, 16, 33, 48, 64], 256 << 20)
+    if args.only and want("c3full"):   # every width of both tables, 1 GiB encoded (output capped at 16 GiB)
+        bench_bitunpack(ctx, stream, 32, list(range(1, 33)), 1 << 30, out_cap=16 << 30)
+        bench_bitunpack(ctx, stream, 64, list(range(1, 65)), 1 << 30, out_cap=16 << 30)
     if want("c4"):
         bench_nested(ctx, stream, args.pages, 20000)
     if want("c2x"):
