@@ -114,6 +114,8 @@ int pq_ctx_synchronize(pq_ctx *ctx);
  * cut.  Both options apply to plans created after the call. */
 #define PQ_OPT_SEGMENT_MAX_PAGES 3
 #define PQ_OPT_SEGMENT_BYTES 4
+/* PQ_OPT_CHUNK_SLOTS: pipeline slots of pq_decode_chunks, 1..8 (default 3). */
+#define PQ_OPT_CHUNK_SLOTS 5
 int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value);
 const char *pq_status_string(int status);
 const char *pq_last_error(pq_ctx *ctx); /* text of the last HIP failure on ctx */
@@ -280,6 +282,42 @@ int pq_decode_pages(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, cons
                     size_t src_bytes, void *values, size_t values_bytes, void *levels,
                     size_t levels_bytes, const void *dict, size_t dict_bytes,
                     pq_page_result *results);
+
+/* ---- column chunks from host memory, pipelined ------------------------------------------------
+ * The loop over a row group's column chunks (readRowGroup, file-reader.go:156-191) with each
+ * chunk's pages handed over at once (readPageData, file-reader.go:268-302): one job = one chunk's
+ * descriptor table and its host buffers, offsets relative to those buffers, as for
+ * pq_decode_pages.  The jobs run through three pipeline slots of the context (a stream, device
+ * staging and pinned host staging each), so that the copy to the device of one chunk, the decode of
+ * another and the copy back of a third overlap; the call returns when every job is done and its
+ * values, levels and results are in the caller's memory.
+ * The caller's buffers may be ordinary pageable memory (what cgo hands over): the library copies
+ * through pinned staging of its own with a few host threads.  PQ_CHUNKS_PINNED promises that src,
+ * values, levels and dict of every job came from pq_host_alloc: they are then copied to and from
+ * directly.  job.status: PQ_OK, or why this job's descriptors were refused (PQ_ERR_BAD_ARGUMENT,
+ * PQ_ERR_OUT_OF_RANGE) — the other jobs still run; the per-page outcome is in job.results.  Returns
+ * PQ_OK or PQ_ERR_HIP / PQ_ERR_BAD_ARGUMENT for the call as a whole.  Contexts with a stream of the
+ * caller's: the slots use streams of their own, the caller's stream is not involved. */
+typedef struct pq_chunk_job {
+    const pq_page_desc *descs;
+    size_t n_pages;
+    const void *src;
+    size_t src_bytes;
+    void *values;
+    size_t values_bytes;
+    void *levels;
+    size_t levels_bytes;
+    const void *dict;
+    size_t dict_bytes;
+    pq_page_result *results; /* n_pages */
+    int32_t status;          /* out */
+    int32_t reserved;
+} pq_chunk_job;
+#define PQ_CHUNKS_PINNED 1u
+int pq_decode_chunks(pq_ctx *ctx, pq_chunk_job *jobs, size_t n_jobs, uint32_t flags);
+/* Pinned host memory for PQ_CHUNKS_PINNED (hipHostMalloc / hipHostFree). */
+void *pq_host_alloc(pq_ctx *ctx, size_t bytes);
+void pq_host_free(pq_ctx *ctx, void *p);
 
 /* ---- single-stream conveniences (host memory), one call per reference call --
  * hybrid:  HybridDecoder.Init/InitSize + n x Next()   (encoding/hybrid-decoder.go:42-109)

@@ -28,6 +28,7 @@ OPT_DELTA_WAVE_MIN_PAGES = 1
 OPT_HYBRID_WAVE_MIN_PAGES = 2
 OPT_SEGMENT_MAX_PAGES = 3
 OPT_SEGMENT_BYTES = 4
+OPT_CHUNK_SLOTS = 5
 
 STAGE_NONE, STAGE_REP_INIT, STAGE_DEF_INIT, STAGE_VALUES_INIT, STAGE_REP, STAGE_DEF, STAGE_VALUES = range(7)
 
@@ -36,6 +37,7 @@ EXPORTS = [
     "pq_last_error",
     "pq_version", "pq_bitunpack32_dev", "pq_bitunpack64_dev", "pq_bitunpack32", "pq_bitunpack64",
     "pq_plan_create", "pq_plan_run", "pq_plan_results", "pq_plan_segments", "pq_plan_destroy", "pq_decode_pages",
+    "pq_decode_chunks", "pq_host_alloc", "pq_host_free",
     "pq_hybrid_decode", "pq_dict_decode", "pq_levels_decode", "pq_delta_decode32",
     "pq_delta_decode64", "pq_plain_decode", "pq_bool_plain_decode",
     "pq_levels_pack_dev", "pq_levels_pack", "pq_column_entries_dev", "pq_column_entries", "pq_column_entries_noalloc",
@@ -57,6 +59,16 @@ class PageResult(C.Structure):
     _fields_ = [("status", C.c_int32), ("stage", C.c_int32), ("detail", C.c_int32),
                 ("n_decoded", C.c_uint32), ("not_null", C.c_uint32), ("n_levels", C.c_uint32),
                 ("consumed", C.c_uint64)]
+
+
+class ChunkJob(C.Structure):
+    _fields_ = [("descs", C.c_void_p), ("n_pages", C.c_size_t), ("src", C.c_void_p), ("src_bytes", C.c_size_t),
+                ("values", C.c_void_p), ("values_bytes", C.c_size_t), ("levels", C.c_void_p),
+                ("levels_bytes", C.c_size_t), ("dict", C.c_void_p), ("dict_bytes", C.c_size_t),
+                ("results", C.c_void_p), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+CHUNKS_PINNED = 1
 
 
 class EntriesResult(C.Structure):
@@ -127,6 +139,11 @@ def load():
         lib.pq_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         lib.pq_plan_results.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pq_decode_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
+        lib.pq_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+        lib.pq_host_alloc.restype = C.c_void_p
+        lib.pq_host_free.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pq_host_free.restype = None
         lib.pq_plan_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         lib.pq_decode_pages.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
@@ -309,6 +326,41 @@ class Context:
         return results, values, levels
 
     # ---- device-resident entry points (raw device pointers) ----
+    def decode_chunks(self, jobs, pinned=False):
+        """pq_decode_chunks.  jobs: list of dicts with descs (DESC_DTYPE array), src, values, levels, dict
+        (uint8 numpy arrays or None; outputs are written in place).  -> list of (status, results)"""
+        n = len(jobs)
+        arr = (ChunkJob * max(n, 1))()
+        keep = []
+        for i, j in enumerate(jobs):
+            d = np.ascontiguousarray(j["descs"], dtype=DESC_DTYPE)
+            res = np.zeros(max(d.size, 1), dtype=RESULT_DTYPE)
+            keep.append((d, res))
+            a = arr[i]
+            a.descs, a.n_pages = d.ctypes.data, d.size
+            for name in ("src", "values", "levels", "dict"):
+                buf = j.get(name)
+                if buf is not None and buf.size:
+                    assert buf.dtype == np.uint8 and buf.flags["C_CONTIGUOUS"]
+                    setattr(a, name, buf.ctypes.data)
+                    setattr(a, name + "_bytes", buf.size)
+            a.results = res.ctypes.data
+        st = self._lib.pq_decode_chunks(self._h, arr, n, CHUNKS_PINNED if pinned else 0)
+        if st != OK:
+            raise PqError(st, "(pq_decode_chunks) " + self._lib.pq_last_error(self._h).decode())
+        return [(int(arr[i].status), keep[i][1][: keep[i][0].size]) for i in range(n)]
+
+    def host_alloc(self, nbytes):
+        """pq_host_alloc as a uint8 numpy array (pinned); free with host_free(array)."""
+        p = self._lib.pq_host_alloc(self._h, int(nbytes))
+        if not p:
+            raise PqError(ERR_HIP, "(pq_host_alloc) " + self._lib.pq_last_error(self._h).decode())
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(int(nbytes),))
+        return a
+
+    def host_free(self, array):
+        self._lib.pq_host_free(self._h, C.c_void_p(array.ctypes.data))
+
     def delta_length_ba_decode(self, src, n):
         """ByteArrayDeltaLengthDecoder.Init + DecodeValues(dest[:n]) -> dict(status, init_failed, n_decoded,
         consumed, offsets[:n_decoded + 1], data[:offsets[-1]])."""

@@ -10,6 +10,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pq_launch.hpp"
@@ -44,6 +45,26 @@ struct pq_ctx {
     unsigned host_img_next = 0;
     // plans made from this context and not yet destroyed: pq_ctx_destroy detaches them
     std::vector<pq_plan *> live_plans;
+    // pq_decode_chunks: pipeline slots, each a context of its own (stream, device staging) plus
+    // pinned host staging for callers whose memory is pageable
+    struct ChunkSlot *slots = nullptr;
+    int n_slots = 3;  // slots pq_decode_chunks uses (PQ_OPT_CHUNK_SLOTS)
+    // all copies to the device go through one stream and all copies back through another, so that
+    // each direction's copies queue up behind one another without gaps
+    hipStream_t chunk_in = nullptr, chunk_out = nullptr;
+};
+
+constexpr int kChunkSlotsMax = 8;
+constexpr int kCopyThreads = 4;
+
+struct ChunkSlot {
+    pq_ctx *sub = nullptr;
+    void *pin_in = nullptr, *pin_out = nullptr;   // src | dict, values | levels | results
+    size_t pin_in_cap = 0, pin_out_cap = 0;
+    hipEvent_t copied_in = nullptr, decoded = nullptr, done = nullptr;
+    pq_plan *plan = nullptr;
+    pq_chunk_job *job = nullptr;  // in flight
+    size_t off_levels = 0, off_results = 0;
 };
 
 struct pq_plan {
@@ -276,6 +297,22 @@ void pq_ctx_destroy(pq_ctx *ctx)
         p->d_descs = nullptr;
         p->ctx = nullptr;
     }
+    if (ctx->slots) {
+        for (int k = 0; k < kChunkSlotsMax; ++k) {
+            ChunkSlot &sl = ctx->slots[k];
+            if (sl.plan) pq_plan_destroy(sl.plan);
+            if (sl.sub) pq_ctx_destroy(sl.sub);
+            if (sl.pin_in) (void)hipHostFree(sl.pin_in);
+            if (sl.pin_out) (void)hipHostFree(sl.pin_out);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+            if (sl.copied_in) (void)hipEventDestroy(sl.copied_in);
+            if (sl.decoded) (void)hipEventDestroy(sl.decoded);
+        }
+        delete[] ctx->slots;
+        if (ctx->chunk_in) (void)hipStreamDestroy(ctx->chunk_in);
+        if (ctx->chunk_out) (void)hipStreamDestroy(ctx->chunk_out);
+        (void)hipSetDevice(ctx->device);
+    }
     if (ctx->spare_block) (void)hipFree(ctx->spare_block);
     for (int i = 0; i < 2; ++i) {
         if (ctx->host_img[i]) (void)hipHostFree(ctx->host_img[i]);
@@ -308,6 +345,10 @@ int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value)
     case PQ_OPT_SEGMENT_MAX_PAGES:
         if (value < 0) return PQ_ERR_BAD_ARGUMENT;
         ctx->seg_max_pages = value > 0xffffffffll ? 0xffffffffu : (uint32_t)value;
+        return PQ_OK;
+    case PQ_OPT_CHUNK_SLOTS:
+        if (value < 1 || value > kChunkSlotsMax) return PQ_ERR_BAD_ARGUMENT;
+        ctx->n_slots = (int)value;
         return PQ_OK;
     case PQ_OPT_SEGMENT_BYTES:
         // a segment holds at least one block header (a 256-value block is at most 1038 bytes)
@@ -720,6 +761,193 @@ int pq_decode_pages(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, cons
         return done(PQ_ERR_HIP);
     st = pq_plan_results(plan, results);
     return done(st);
+}
+
+// ---- column chunks from host memory, pipelined ---------------------------------------------
+
+namespace {
+
+// dst <- src with a few threads: one host core copies at about half the rate of a PCIe link
+void par_copy(void *dst, const void *src, size_t n)
+{
+    if (n < (8u << 20)) {
+        std::memcpy(dst, src, n);
+        return;
+    }
+    std::thread th[kCopyThreads - 1];
+    const size_t piece = (n / kCopyThreads + 63) & ~(size_t)63;
+    for (int t = 0; t < kCopyThreads - 1; ++t) {
+        const size_t lo = std::min(n, (size_t)(t + 1) * piece), hi = std::min(n, (size_t)(t + 2) * piece);
+        th[t] = std::thread([=] { if (hi > lo) std::memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+    }
+    std::memcpy(dst, src, std::min(n, piece));
+    for (auto &t : th) t.join();
+}
+
+int ensure_pinned(pq_ctx *ctx, void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return PQ_OK;
+    if (*p) {
+        PQ_HIP(ctx, hipHostFree(*p));
+        *p = nullptr;
+        *cap = 0;
+    }
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 1u << 20);
+    PQ_HIP(ctx, hipHostMalloc(p, want, hipHostMallocDefault));
+    *cap = want;
+    return PQ_OK;
+}
+
+size_t up256(size_t x) { return (x + 255) / 256 * 256; }
+
+// Waits for the slot's job and hands its outputs to the caller.
+int finish_slot(pq_ctx *ctx, ChunkSlot &sl, bool pinned)
+{
+    if (!sl.job) return PQ_OK;
+    pq_chunk_job &j = *sl.job;
+    sl.job = nullptr;
+    PQ_HIP(ctx, hipEventSynchronize(sl.done));
+    if (!pinned) {
+        const char *out = static_cast<const char *>(sl.pin_out);
+        if (j.values_bytes) par_copy(j.values, out, j.values_bytes);
+        if (j.levels_bytes) par_copy(j.levels, out + sl.off_levels, j.levels_bytes);
+    }
+    std::memcpy(j.results, static_cast<const char *>(sl.pin_out) + sl.off_results, j.n_pages * sizeof(pq_page_result));
+    pq_plan_destroy(sl.plan);
+    sl.plan = nullptr;
+    return PQ_OK;
+}
+
+// Queues one job on the slot's stream: copies in, decode, copies out, an event behind them.
+int start_slot(pq_ctx *ctx, ChunkSlot &sl, pq_chunk_job &j, bool pinned)
+{
+    pq_ctx *sub = sl.sub;
+    j.status = PQ_OK;
+    if (j.n_pages == 0) return PQ_OK;
+    if (!j.descs || !j.results || (j.src_bytes && !j.src) || (j.values_bytes && !j.values) ||
+        (j.levels_bytes && !j.levels) || (j.dict_bytes && !j.dict)) {
+        j.status = PQ_ERR_BAD_ARGUMENT;
+        return PQ_OK;
+    }
+    const size_t sizes[4] = {j.src_bytes, j.values_bytes, j.levels_bytes, j.dict_bytes};
+    for (int i = 0; i < 4; ++i) {
+        const int st = ensure_stage(sub, i, sizes[i] + 16);
+        if (st != PQ_OK) {
+            ctx->last_error = sub->last_error;
+            return st;
+        }
+    }
+    sl.off_levels = up256(j.values_bytes);
+    sl.off_results = pinned ? 0 : sl.off_levels + up256(j.levels_bytes);
+    int st = ensure_pinned(ctx, &sl.pin_out, &sl.pin_out_cap, sl.off_results + j.n_pages * sizeof(pq_page_result));
+    const size_t off_dict = up256(j.src_bytes);
+    if (st == PQ_OK && !pinned) st = ensure_pinned(ctx, &sl.pin_in, &sl.pin_in_cap, off_dict + j.dict_bytes);
+    if (st != PQ_OK) return st;
+    st = pq_plan_create(sub, j.descs, j.n_pages, &sl.plan);  // before anything is queued: it may refuse the job
+    if (st != PQ_OK) {
+        j.status = st;
+        sl.plan = nullptr;
+        if (st == PQ_ERR_HIP) ctx->last_error = sub->last_error;
+        return st == PQ_ERR_HIP ? st : PQ_OK;
+    }
+    const void *h_src = j.src, *h_dict = j.dict;
+    if (!pinned) {
+        char *in = static_cast<char *>(sl.pin_in);
+        if (j.src_bytes) par_copy(in, j.src, j.src_bytes);
+        if (j.dict_bytes) std::memcpy(in + off_dict, j.dict, j.dict_bytes);
+        h_src = in;
+        h_dict = in + off_dict;
+    }
+    // copies in on the one stream, the decode on the slot's, copies out on the other; the slot's
+    // device buffers are free: the job that used them last has been waited for
+    if (j.src_bytes) PQ_HIP(ctx, hipMemcpyAsync(sub->stage[0], h_src, j.src_bytes, hipMemcpyHostToDevice, ctx->chunk_in));
+    if (j.dict_bytes) PQ_HIP(ctx, hipMemcpyAsync(sub->stage[3], h_dict, j.dict_bytes, hipMemcpyHostToDevice, ctx->chunk_in));
+    PQ_HIP(ctx, hipEventRecord(sl.copied_in, ctx->chunk_in));
+    hipStream_t s = sub->stream;
+    PQ_HIP(ctx, hipStreamWaitEvent(s, sl.copied_in, 0));
+    st = pq_plan_run(sl.plan, sub->stage[0], j.src_bytes, sub->stage[1], j.values_bytes, sub->stage[2], j.levels_bytes,
+                     sub->stage[3], j.dict_bytes);
+    if (st != PQ_OK) {  // a descriptor points outside the job's buffers: the other jobs go on
+        j.status = st;
+        PQ_HIP(ctx, hipStreamSynchronize(ctx->chunk_in));  // the copies in still read the slot's staging
+        pq_plan_destroy(sl.plan);
+        sl.plan = nullptr;
+        if (st == PQ_ERR_HIP) ctx->last_error = sub->last_error;
+        return st == PQ_ERR_HIP ? st : PQ_OK;
+    }
+    PQ_HIP(ctx, hipEventRecord(sl.decoded, s));
+    PQ_HIP(ctx, hipStreamWaitEvent(ctx->chunk_out, sl.decoded, 0));
+    char *out = static_cast<char *>(sl.pin_out);
+    void *h_values = pinned ? j.values : out, *h_levels = pinned ? j.levels : out + sl.off_levels;
+    if (j.values_bytes)
+        PQ_HIP(ctx, hipMemcpyAsync(h_values, sub->stage[1], j.values_bytes, hipMemcpyDeviceToHost, ctx->chunk_out));
+    if (j.levels_bytes)
+        PQ_HIP(ctx, hipMemcpyAsync(h_levels, sub->stage[2], j.levels_bytes, hipMemcpyDeviceToHost, ctx->chunk_out));
+    PQ_HIP(ctx, hipMemcpyAsync(out + sl.off_results, sl.plan->d_results, j.n_pages * sizeof(pq_page_result),
+                               hipMemcpyDeviceToHost, ctx->chunk_out));
+    PQ_HIP(ctx, hipEventRecord(sl.done, ctx->chunk_out));
+    sl.job = &j;
+    return PQ_OK;
+}
+
+} // namespace
+
+int pq_decode_chunks(pq_ctx *ctx, pq_chunk_job *jobs, size_t n_jobs, uint32_t flags)
+{
+    if (!ctx || (n_jobs && !jobs) || (flags & ~(uint32_t)PQ_CHUNKS_PINNED)) return PQ_ERR_BAD_ARGUMENT;
+    if (n_jobs == 0) return PQ_OK;
+    const bool pinned = (flags & PQ_CHUNKS_PINNED) != 0;
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->slots) {
+        ctx->slots = new (std::nothrow) ChunkSlot[kChunkSlotsMax];
+        if (!ctx->slots) return PQ_ERR_BAD_ARGUMENT;
+    }
+    const size_t n_slots = (size_t)ctx->n_slots;
+    for (size_t k = 0; k < n_slots; ++k) {
+        ChunkSlot &sl = ctx->slots[k];
+        if (!sl.sub) {
+            const int st = pq_ctx_create(ctx->device, nullptr, &sl.sub);
+            if (st != PQ_OK) return st;
+        }
+        sl.sub->delta_wave_min_pages = ctx->delta_wave_min_pages;
+        sl.sub->hybrid_wave_min_pages = ctx->hybrid_wave_min_pages;
+        sl.sub->seg_max_pages = ctx->seg_max_pages;
+        sl.sub->seg_bytes = ctx->seg_bytes;
+        if (!sl.done) PQ_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        if (!sl.copied_in) PQ_HIP(ctx, hipEventCreateWithFlags(&sl.copied_in, hipEventDisableTiming));
+        if (!sl.decoded) PQ_HIP(ctx, hipEventCreateWithFlags(&sl.decoded, hipEventDisableTiming));
+    }
+    if (!ctx->chunk_in) PQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->chunk_in, hipStreamNonBlocking));
+    if (!ctx->chunk_out) PQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->chunk_out, hipStreamNonBlocking));
+    int rc = PQ_OK;
+    for (size_t i = 0; i < n_jobs && rc == PQ_OK; ++i) {
+        ChunkSlot &sl = ctx->slots[i % n_slots];
+        rc = finish_slot(ctx, sl, pinned);        // the job that had the slot, n_slots jobs ago
+        if (rc == PQ_OK) rc = start_slot(ctx, sl, jobs[i], pinned);
+    }
+    // drain, oldest first
+    for (size_t d = 0; d < n_slots; ++d) {
+        ChunkSlot &sl = ctx->slots[(n_jobs + d) % n_slots];
+        const int st = finish_slot(ctx, sl, pinned);
+        if (rc == PQ_OK) rc = st;
+    }
+    return rc;
+}
+
+void *pq_host_alloc(pq_ctx *ctx, size_t bytes)
+{
+    if (!ctx || bytes == 0) return nullptr;
+    void *p = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    if (!hip_ok(ctx, hipHostMalloc(&p, bytes, hipHostMallocDefault), "hipHostMalloc")) return nullptr;
+    return p;
+}
+
+void pq_host_free(pq_ctx *ctx, void *p)
+{
+    if (!ctx || !p) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipHostFree(p);
 }
 
 // ---- single-stream conveniences -------------------------------------------------
