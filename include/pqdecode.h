@@ -108,7 +108,10 @@ int pq_ctx_synchronize(pq_ctx *ctx);
 /* PQ_OPT_SEGMENT_MAX_PAGES: a plan with fewer than this many DELTA32 (or DELTA64) descriptors has
  * its large ones decoded in segments, many waves to a page (a page is one serial chain of blocks,
  * encoding/delta-binary-packed-decoder.go:130-147; a few large pages would otherwise leave most of
- * the machine idle).  Default 2048; 0 = never.  Results are the same either way.
+ * the machine idle; measured on MI355X the cut pays below about 1000 pages, whatever their size).
+ * Dictionary-index pages (PQ_KIND_DICT) and raw hybrid streams (PQ_KIND_HYBRID without flags)
+ * whose runs are bit-packed runs of one repeated length (encoding/hybrid-decoder.go:111-136) are cut
+ * the same way under the same option.  Default 1024; 0 = never.  Results are the same either way.
  * PQ_OPT_SEGMENT_BYTES: bytes of the stream per segment, a multiple of 16 from 2048 on; 0 (the
  * default) = chosen from the plan's size, 8 to 64 KiB.  Pages shorter than three segments are not
  * cut.  Both options apply to plans created after the call. */

@@ -27,7 +27,7 @@ struct pq_ctx {
     uint32_t hybrid_wave_min_pages = 1;
     // delta pages are cut into segments when a plan has fewer than seg_max_pages of one element
     // size; seg_bytes != 0 fixes the segment length (else it follows the plan's size)
-    uint32_t seg_max_pages = 2048;
+    uint32_t seg_max_pages = 1024;
     uint32_t seg_bytes = 0;
     void *stage[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t stage_cap[4] = {0, 0, 0, 0};
@@ -92,6 +92,11 @@ struct pq_plan {
     pq::SegPage *d_seg_pages[2] = {nullptr, nullptr};
     uint32_t *d_seg_owner[2] = {nullptr, nullptr};
     pq::SegRec *d_seg_recs[2] = {nullptr, nullptr};
+    // hybrid / dictionary descriptors decoded in segments: the last n_hseg_pages ids of group 0
+    uint32_t n_hseg_pages = 0, n_hseg_segs = 0, n_hseg_checks = 0;
+    pq::HsegPage *d_hseg_pages = nullptr;
+    uint32_t *d_hseg_seg_owner = nullptr, *d_hseg_check_owner = nullptr, *d_hseg_counts = nullptr;
+    pq::HsegRec *d_hseg_recs = nullptr;
 };
 
 namespace {
@@ -536,6 +541,42 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
         plan->n_seg_pages[k] = (uint32_t)seg_pages[k].size();
         plan->n_segs[k] = (uint32_t)seg_owner[k].size();
     }
+    // The same for dictionary-index pages and raw hybrid streams (seghybrid.hip).
+    std::vector<pq::HsegPage> hseg_pages;
+    std::vector<uint32_t> hseg_seg_owner, hseg_check_owner;
+    if (!ids[0].empty() && ids[0].size() < ctx->seg_max_pages) {
+        std::vector<uint32_t> &g = ids[0];
+        uint64_t bytes = 0;
+        for (uint32_t i : g) bytes += descs[i].src_len;
+        uint64_t L = ctx->seg_bytes;
+        if (L == 0) {
+            L = 8192;
+            while (L < 65536 && L * 16384 < bytes) L *= 2;
+        }
+        auto cut = [&](uint32_t i) {
+            const pq_page_desc &d = descs[i];
+            return (d.kind == PQ_KIND_DICT || (d.kind == PQ_KIND_HYBRID && d.flags == 0u)) && d.src_len >= 3 * L &&
+                   d.src_len < 0x7fffffffull && d.n_values >= 4096u;
+        };
+        std::stable_partition(g.begin(), g.end(), [&](uint32_t i) { return !cut(i); });
+        for (uint32_t i : g) {
+            if (!cut(i)) continue;
+            pq::HsegPage pg;
+            std::memset(&pg, 0, sizeof pg);
+            pg.desc = i;
+            pg.seg_first = (uint32_t)hseg_seg_owner.size();
+            pg.n_segs = (uint32_t)(2 * ((descs[i].src_len + L - 1) / L) + 2);
+            pg.seg_bytes = (uint32_t)L;
+            pg.check_first = (uint32_t)hseg_check_owner.size();
+            pg.n_checks = (uint32_t)((descs[i].src_len + 4095) / 4096);
+            hseg_seg_owner.insert(hseg_seg_owner.end(), pg.n_segs, (uint32_t)hseg_pages.size());
+            hseg_check_owner.insert(hseg_check_owner.end(), pg.n_checks, (uint32_t)hseg_pages.size());
+            hseg_pages.push_back(pg);
+        }
+        plan->n_hseg_pages = (uint32_t)hseg_pages.size();
+        plan->n_hseg_segs = (uint32_t)hseg_seg_owner.size();
+        plan->n_hseg_checks = (uint32_t)hseg_check_owner.size();
+    }
     std::vector<uint32_t> all;
     all.reserve(n_pages);
     for (int g = 0; g < 4; ++g) {
@@ -558,8 +599,10 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
             sob[k] = up(seg_owner[k].size() * sizeof(uint32_t));
             srb[k] = up(seg_owner[k].size() * sizeof(pq::SegRec));
         }
-        const size_t img = db + ib + kFlagBytes + spb[0] + sob[0] + spb[1] + sob[1];
-        const size_t total = img + rb + srb[0] + srb[1];
+        const size_t hpb = up(hseg_pages.size() * sizeof(pq::HsegPage)), hsb = up(hseg_seg_owner.size() * sizeof(uint32_t));
+        const size_t hcb = up(hseg_check_owner.size() * sizeof(uint32_t)), hrb = up(hseg_seg_owner.size() * sizeof(pq::HsegRec));
+        const size_t img = db + ib + kFlagBytes + spb[0] + sob[0] + spb[1] + sob[1] + hpb + hsb + hcb;
+        const size_t total = img + rb + srb[0] + srb[1] + hrb + hcb;
         uint8_t *block = nullptr;
         hipError_t e = hipSuccess;
         if (ctx->spare_block && ctx->spare_bytes >= total) {
@@ -604,6 +647,18 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
                 plan->d_seg_recs[k] = reinterpret_cast<pq::SegRec *>(block + rec_at);
                 rec_at += srb[k];
             }
+            plan->d_hseg_pages = reinterpret_cast<pq::HsegPage *>(block + at);
+            if (!hseg_pages.empty()) std::memcpy(h + at, hseg_pages.data(), hseg_pages.size() * sizeof(pq::HsegPage));
+            at += hpb;
+            plan->d_hseg_seg_owner = reinterpret_cast<uint32_t *>(block + at);
+            if (!hseg_seg_owner.empty()) std::memcpy(h + at, hseg_seg_owner.data(), hseg_seg_owner.size() * sizeof(uint32_t));
+            at += hsb;
+            plan->d_hseg_check_owner = reinterpret_cast<uint32_t *>(block + at);
+            if (!hseg_check_owner.empty())
+                std::memcpy(h + at, hseg_check_owner.data(), hseg_check_owner.size() * sizeof(uint32_t));
+            at += hcb;
+            plan->d_hseg_recs = reinterpret_cast<pq::HsegRec *>(block + rec_at);
+            plan->d_hseg_counts = reinterpret_cast<uint32_t *>(block + rec_at + hrb);
             e = hipMemcpyAsync(block, h, img, hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess) e = hipEventRecord(ctx->host_img_done[slot], ctx->stream);
         } else if (block) {
@@ -668,8 +723,13 @@ int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_valu
     pq::PageBuffers buf{(const uint8_t *)d_src, (uint8_t *)d_values, (uint8_t *)d_levels,
                         (const uint8_t *)d_dict};
     const pq::WaveLaunch wl{ctx->hybrid_wave_min_pages, plan->shared_dict_bytes, plan->shared_dict_off};
+    PQ_HIP(ctx, pq::launch_seg_hybrid(ctx->stream, plan->d_descs, plan->d_hseg_pages, plan->n_hseg_pages,
+                                      plan->d_hseg_check_owner, plan->n_hseg_checks, plan->d_hseg_counts,
+                                      plan->d_hseg_seg_owner, plan->n_hseg_segs, plan->d_hseg_recs, buf, plan->d_results,
+                                      plan->shared_dict_bytes, plan->shared_dict_off));
     PQ_HIP(ctx, pq::launch_stream_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[0],
-                                        plan->count[0], buf, plan->d_results, plan->dict_lds_bytes, wl));
+                                        plan->count[0] - plan->n_hseg_pages, buf, plan->d_results, plan->dict_lds_bytes,
+                                        wl));
     plan->epoch += 1;
     if (plan->epoch == 0) plan->epoch = 1; // 0 is what the flag words start as
     bool serial32 = false, serial64 = false;

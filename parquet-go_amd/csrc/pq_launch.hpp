@@ -94,6 +94,43 @@ hipError_t launch_seg_delta(hipStream_t s, int bits, const pq_page_desc *d_descs
                             const uint32_t *d_owner, uint32_t n_segs, SegRec *d_recs, PageBuffers buf,
                             pq_page_result *d_results, uint32_t *d_flag, uint32_t epoch);
 
+// ---- segmented hybrid streams (seghybrid.hip) ---------------------------------------------------
+// One record per dictionary-index / raw hybrid page that is cut into segments.  The host fills the
+// first six fields; the rest is written on the device every run.
+struct HsegPage {
+    uint32_t desc;         // index of the page's descriptor
+    uint32_t seg_first;    // index of its first segment record
+    uint32_t n_segs;       // segment records it owns
+    uint32_t seg_bytes;    // bytes of the stream a segment aims at
+    uint32_t check_first;  // index of its first run-check counter
+    uint32_t n_checks;     // counters it owns (64 runs each)
+    uint32_t whole;        // 1: not a chain of equal bit-packed runs, segment 0 decodes the whole page
+    uint32_t w;            // bit width
+    uint32_t pos0;         // stream offset of the first run header
+    uint32_t stride;       // bytes from one run header to the next
+    uint32_t vpr;          // values per run
+    uint32_t head;         // the run header's bytes
+    uint32_t hl;           // and how many they are
+    uint32_t runs_per_seg;
+    uint32_t n_part;       // segments of proven runs; the tail is segment n_part
+    uint32_t pad;
+};
+struct HsegRec {
+    uint64_t off;        // stream offset the segment starts at
+    uint32_t v0;         // index of its first value
+    uint32_t count;      // values it decodes
+    uint32_t flags;      // kSeg*
+    int32_t status;      // what its decode returned
+    uint32_t n_decoded;
+    uint32_t pad;
+    uint64_t consumed;
+};
+// d_check_owner / d_seg_owner: counter -> page and segment -> page maps.
+hipError_t launch_seg_hybrid(hipStream_t s, const pq_page_desc *d_descs, HsegPage *d_pages, uint32_t n_pages,
+                             const uint32_t *d_check_owner, uint32_t n_checks, uint32_t *d_counts,
+                             const uint32_t *d_seg_owner, uint32_t n_segs, HsegRec *d_recs, PageBuffers buf,
+                             pq_page_result *d_results, uint32_t dict_lds_bytes, uint64_t dict_lds_off);
+
 // Level post-processing (assemble.hip).  d_out: ceil(n / 8) * w bytes, 4-byte aligned.
 hipError_t launch_levels_pack(hipStream_t s, const int32_t *d_levels, uint64_t n, int w, uint8_t *d_out);
 // d_work: entries_workspace_bytes(n) bytes, 8-byte aligned; d_validity: 4 * ceil(n / 32) bytes.

@@ -44,7 +44,7 @@ def _run(ctx, cases, bits, seg_bytes, seed=0):
             for c in cases:
                 _check(c, bits)
     finally:
-        ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 2048)
+        ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 1024)
         ctx.set_option(K.OPT_SEGMENT_BYTES, 0)
 
 
@@ -93,7 +93,7 @@ def test_one_million_value_pages(ctx, bits):
             c.result_src_len = cut
             cases.append(c)
     try:
-        ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 2048)
+        ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 1024)
         ctx.set_option(K.OPT_SEGMENT_BYTES, 0)
         run_cases(ctx, cases, seed=2)
         for c in cases:
@@ -206,3 +206,102 @@ def test_a_healthy_page_is_decoded_by_all_its_segments(ctx):
         apart = int((segs["decode"] != 0).sum())
         assert apart >= segs.size - 2, (bits, wmax, block, apart, segs.size)
         assert int((segs["decode"] == 2).sum()) == 1
+
+
+# ---------------------------------------------------------------------------
+# dictionary-index pages and raw hybrid streams in segments (runs of one repeated header)
+
+def _bp_stream(keys, w, groups_per_run):
+    """Bit-packed runs of groups_per_run groups each (the last one shorter), any header length."""
+    keys = np.asarray(keys, dtype=np.int64)
+    g = (keys.size + 7) // 8
+    padded = np.concatenate([keys, np.zeros(g * 8 - keys.size, np.int64)])
+    packed = synth.pack_bits(padded, w).reshape(g, w)
+    out = []
+    for lo in range(0, g, groups_per_run):
+        hi = min(g, lo + groups_per_run)
+        out.append(np.array(synth.uleb128(((hi - lo) << 1) | 1), dtype=np.uint8))
+        out.append(packed[lo:hi].reshape(-1))
+    return np.concatenate(out)
+
+
+def _check_hybrid(c):
+    if c.kind == K.KIND_DICT:
+        st, want, nd, consumed = O.dict_decode(c.src[: c.result_src_len], c.dictionary, c.n)
+    else:
+        st, want, consumed = O.hybrid_decode(c.src[: c.result_src_len], c.bit_width, c.n, False)
+        nd = want.size
+    r = c.result
+    assert r["status"] == st, (c.tag, r, st, nd)
+    assert r["n_decoded"] == nd, (c.tag, r, nd)
+    if st != K.DICT_INVALID_INDEX:
+        assert np.array_equal(c.values[:nd], want[:nd]), c.tag
+    assert guard_ok(c.guard), c.tag
+    if st == O.OK:
+        assert r["consumed"] == consumed, (c.tag, r, consumed)
+
+
+def _hybrid_cases(rng):
+    cases = []
+
+    def add(tag, kind, stream, n, **kw):
+        c = Case(kind, stream, n, **kw)
+        c.result_src_len = stream.size
+        c.tag = tag
+        cases.append(c)
+        return c
+    d32 = rng.integers(-2**31, 2**31, size=4096, dtype=np.int64).astype(np.int32)
+    d64 = rng.integers(-2**62, 2**62, size=700, dtype=np.int64)
+    n = 300_000
+    keys = rng.integers(0, 4096, size=n)
+    page = np.concatenate([[12], synth.hybrid_encode_bitpacked(keys, 12)]).astype(np.uint8)
+    for pull in (n, n - 1, n + 5, n // 2, 504 * 40, 504 * 40 + 1, 4096):
+        add("dict w=12 pull %d" % pull, K.KIND_DICT, page, pull, dictionary=d32)
+    for cut in (page.size - 1, page.size - 400, page.size // 2, page.size // 2 + 1, 30000, 757 * 50 + 1, 757 * 50 + 2):
+        c = add("dict w=12 cut %d" % cut, K.KIND_DICT, page[:cut].copy(), n, dictionary=d32)
+    # 8-byte dictionary entries, 10-bit keys
+    k10 = rng.integers(0, 700, size=200_000)
+    add("dict64 w=10", K.KIND_DICT, np.concatenate([[10], synth.hybrid_encode_bitpacked(k10, 10)]).astype(np.uint8),
+        k10.size, dictionary=d64)
+    # a key outside the dictionary in the middle of the page: count 0, "invalid index"
+    bad = keys.copy()
+    bad[n // 2 + 17] = 4095
+    add("dict invalid index", K.KIND_DICT, np.concatenate([[12], synth.hybrid_encode_bitpacked(bad, 12)]).astype(np.uint8),
+        n, dictionary=d32[:4000])
+    # runs of 64 groups (two header bytes), of 5 groups (stride below the limit), of 1000 groups
+    for gpr in (64, 5, 1000, 8):
+        s = _bp_stream(keys[:150_000], 12, gpr)
+        add("dict runs of %d groups" % gpr, K.KIND_DICT, np.concatenate([[12], s]).astype(np.uint8), 150_000,
+            dictionary=d32)
+    # equal runs first, then runs of every kind (the reference encoder on run-heavy keys), then equal runs again
+    mixed = np.concatenate([keys[:100_000], np.repeat(rng.integers(0, 4096, size=2000), 37), keys[:90_000]])
+    add("dict mixed", K.KIND_DICT, synth.dict_page(mixed, w=12), mixed.size, dictionary=d32)
+    # damage: a run header in the middle replaced (other run length; zero-length run)
+    for new in (0x7d, 0x01, 0x00):
+        s = page.copy()
+        s[1 + 757 * 200] = new
+        add("dict header %#x in the middle" % new, K.KIND_DICT, s, n, dictionary=d32)
+    # raw hybrid streams at several widths
+    for w in (1, 3, 7, 16, 20, 32):
+        v = rng.integers(0, 1 << min(w, 31), size=120_000)
+        add("hybrid w=%d" % w, K.KIND_HYBRID, synth.hybrid_encode_bitpacked(v, w), v.size, bit_width=w)
+    # not cut at all: RLE first
+    rl = np.concatenate([np.zeros(64, np.int64), keys[:100_000]])
+    add("dict rle first", K.KIND_DICT, synth.dict_page(rl, w=12), rl.size, dictionary=d32)
+    return cases
+
+
+@pytest.mark.parametrize("seg_bytes", [2048, 8192, 0])
+def test_hybrid_streams_in_segments_vs_oracle(ctx, seg_bytes):
+    rng = np.random.default_rng(900 + seg_bytes)
+    cases = _hybrid_cases(rng)
+    try:
+        for max_pages in (1 << 30, 0):          # cut into segments, and not cut at all
+            ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, max_pages)
+            ctx.set_option(K.OPT_SEGMENT_BYTES, seg_bytes)
+            run_cases(ctx, cases, seed=8)
+            for c in cases:
+                _check_hybrid(c)
+    finally:
+        ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 1024)
+        ctx.set_option(K.OPT_SEGMENT_BYTES, 0)

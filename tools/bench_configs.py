@@ -400,14 +400,14 @@ def main():
         bench_delta(ctx, stream, 1000, 100_000, 64, 16)
         ctx.set_option(capi.OPT_DELTA_WAVE_MIN_PAGES, 1)
     if want("c2seg"):    # large pages cut into segments (the default) against one wave per page
-        for seg in (2048, 0):
+        for seg in (1024, 0):
             ctx.set_option(capi.OPT_SEGMENT_MAX_PAGES, seg)
             lab = ", segmented" if seg else ", one wave per page"
             bench_delta(ctx, stream, 1, 1_000_000, 64, 16, lab)
             bench_delta(ctx, stream, 100, 1_000_000, 64, 16, lab)
             bench_delta(ctx, stream, 1000, 100_000, 64, 16, lab)
             bench_delta(ctx, stream, 100, 1_000_000, 32, 12, lab)
-        ctx.set_option(capi.OPT_SEGMENT_MAX_PAGES, 2048)
+        ctx.set_option(capi.OPT_SEGMENT_MAX_PAGES, 1024)
     if want("plain"):
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_PLAIN, 8, "P PLAIN int64")
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_PLAIN, 4, "P PLAIN int32")
