@@ -500,18 +500,20 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
         const int64_t left = len - c0;
         const uint32_t lim = left > (int64_t)kDwChunk ? (uint32_t)kDwChunk : (left < 0 ? 0u : (uint32_t)left);
         while (true) {
-            if constexpr (LG == 5u && !OFFS) {
+            if constexpr (!OFFS) {
                 // The blocks in the middle of a page — whole, plain, more values wanted behind them —
                 // in a loop of their own with one way out: header walk and decode back to back, no
                 // state handed from one to the other.  Whatever ends it (the page's last block, a
                 // block the window cuts, an unusual header, the segment's end) is left as it is for
-                // the checked code below, which takes one tile and comes back here.
-                const uint32_t o_max = tail ? 0x7fffffffu : (uint32_t)(kDwChunk - kDwBlockMax);
+                // the checked code below, which takes one tile and comes back here.  A block of 256
+                // values is two tiles under one header.
+                constexpr uint32_t kTiles = 1u << (LG - 5u), kBlockValues = 128u * kTiles;
+                const uint32_t o_max = tail ? 0x7fffffffu : (uint32_t)(kDwChunk - kTiles * kDwBlockMax);
                 int32_t stop_rel = 0x7fffffff;
                 if constexpr (SEG) {
                     if (seg_stop >= 0 && seg_stop - c0 < (int64_t)0x7fffffff) stop_rel = (int32_t)(seg_stop - c0);
                 }
-                while (o <= o_max && p0 + 128u < st.need && (int32_t)o < stop_rel) {
+                while (o <= o_max && p0 + kBlockValues < st.need && (int32_t)o < stop_rel && (LG == 5u || blk.half == 0u)) {
                     const uint32_t k = o >> 2, sh = (o & 3u) * 8u;
                     const uint32_t h0 = uni(lds[k]), h1 = uni(lds[k + 1]), h2 = uni(lds[k + 2]);
                     const uint32_t hdr_lo = (uint32_t)(((((uint64_t)h1) << 32) | h0) >> sh);
@@ -520,63 +522,70 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
                     const uint32_t vl = ((uint32_t)__builtin_ctz(end | 0x80000000u) + 1u) >> 3;  // 1..4
                     const uint32_t widths = (uint32_t)(((((uint64_t)mid) << 32) | hdr_lo) >> (8u * vl));
                     const uint32_t data = o + vl + 4u;
-                    const uint32_t next = data + 4u * ((widths * 0x01010101u) >> 24);
+                    const uint32_t next = data + ((((widths * 0x01010101u) >> 24) << LG) >> 3);
                     // minDelta of five bytes and more, a width above 32, a block that is not all in the window
                     if (end == 0u || ((((widths & 0x7f7f7f7fu) + 0x5f5f5f5fu) | widths) & 0x80808080u) != 0u || next > lim)
                         break;
-                    const uint32_t w = __builtin_amdgcn_ubfe(widths, ln.sh8, 8u);
-                    const uint32_t pre = __builtin_amdgcn_ubfe(widths * 0x01010100u, ln.sh8, 8u);
-                    const uint32_t bit = data * 8u + (pre << 5) + ln.k2 * w;
-                    const uint32_t i = bit >> 5, sft = bit & 31u;
-                    const uint32_t e0 = lds[i], e1 = lds[i + 1], e2 = lds[i + 2];
-                    const uint32_t l32 = __builtin_amdgcn_alignbit(e1, e0, sft);
-                    const uint32_t h32 = __builtin_amdgcn_alignbit(e2, e1, sft);
-                    const uint32_t m = (uint32_t)(1ull << w) - 1u;
-                    const uint32_t ua = l32 & m;
-                    const uint32_t ub = (uint32_t)((((uint64_t)h32 << 32) | l32) >> w) & m;
                     const int32_t md = wave_expand_min_delta(hdr_lo, vl);
-                    UT *const q = dst + p0 + 2u * (uint32_t)lane;
-                    if constexpr (sizeof(UT) == 8) {
-                        UT v0, v1;
-                        // every width <= 23 and a minDelta of at most three bytes: the block's partial sums
-                        // fit 32 bits (see wave_decode_tile)
-                        if ((((widths & 0x7f7f7f7fu) + 0x68686868u) & 0x80808080u) == 0u && vl <= 3u) {
-                            const int32_t da = (int32_t)ua + md;
-                            const int32_t pair = da + (int32_t)ub + md;
-                            const int32_t incl = (int32_t)wave_scan_u32((uint32_t)pair);
-                            v0 = carry + (UT)(int64_t)(incl - pair);
-                            v1 = v0 + (UT)(int64_t)da;
-                            carry += (UT)(int64_t)(int32_t)wave_last_u32((uint32_t)incl);
+                    // every width <= 23 and a minDelta of at most three bytes: a tile's partial sums
+                    // fit 32 bits (see wave_decode_tile)
+                    const bool narrow = (((widths & 0x7f7f7f7fu) + 0x68686868u) & 0x80808080u) == 0u && vl <= 3u;
+#pragma unroll
+                    for (uint32_t tile = 0; tile < kTiles; ++tile) {
+                        // this tile's miniblocks: all four widths, or two of them
+                        const uint32_t tw = LG == 5u ? widths : (tile == 0u ? widths & 0xffffu : widths >> 16);
+                        const uint32_t bitbase = data * 8u + (tile == 0u ? 0u : 64u * (((widths & 0xffffu) * 0x0101u >> 8) & 0xffu));
+                        const uint32_t w = __builtin_amdgcn_ubfe(tw, ln.sh8, 8u);
+                        const uint32_t pre = __builtin_amdgcn_ubfe(tw * 0x01010100u, ln.sh8, 8u);
+                        const uint32_t bit = bitbase + (pre << LG) + ln.k2 * w;
+                        const uint32_t i = bit >> 5, sft = bit & 31u;
+                        const uint32_t e0 = lds[i], e1 = lds[i + 1], e2 = lds[i + 2];
+                        const uint32_t l32 = __builtin_amdgcn_alignbit(e1, e0, sft);
+                        const uint32_t h32 = __builtin_amdgcn_alignbit(e2, e1, sft);
+                        const uint32_t m = (uint32_t)(1ull << w) - 1u;
+                        const uint32_t ua = l32 & m;
+                        const uint32_t ub = (uint32_t)((((uint64_t)h32 << 32) | l32) >> w) & m;
+                        UT *const q = dst + p0 + 128u * tile + 2u * (uint32_t)lane;
+                        if constexpr (sizeof(UT) == 8) {
+                            UT v0, v1;
+                            if (narrow) {
+                                const int32_t da = (int32_t)ua + md;
+                                const int32_t pair = da + (int32_t)ub + md;
+                                const int32_t incl = (int32_t)wave_scan_u32((uint32_t)pair);
+                                v0 = carry + (UT)(int64_t)(incl - pair);
+                                v1 = v0 + (UT)(int64_t)da;
+                                carry += (UT)(int64_t)(int32_t)wave_last_u32((uint32_t)incl);
+                            } else {
+                                const UT a = (UT)ua + (UT)(int64_t)md;
+                                const UT pair = a + (UT)ub + (UT)(int64_t)md;
+                                const UT incl = wave_scan_u64(pair);
+                                v0 = carry + (incl - pair);
+                                v1 = v0 + a;
+                                carry += wave_last_u64(incl);
+                            }
+                            if (vec_ok) {
+                                store_nt16(q, (uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32));
+                            } else {
+                                q[0] = v0;
+                                q[1] = v1;
+                            }
                         } else {
-                            const UT a = (UT)ua + (UT)(int64_t)md;
-                            const UT pair = a + (UT)ub + (UT)(int64_t)md;
-                            const UT incl = wave_scan_u64(pair);
-                            v0 = carry + (incl - pair);
-                            v1 = v0 + a;
-                            carry += wave_last_u64(incl);
-                        }
-                        if (vec_ok) {
-                            store_nt16(q, (uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32));
-                        } else {
-                            q[0] = v0;
-                            q[1] = v1;
-                        }
-                    } else {
-                        const UT a = ua + (UT)md;
-                        const UT pair = a + ub + (UT)md;
-                        const UT incl = wave_scan_u32(pair);
-                        const UT v0 = carry + (incl - pair);
-                        const UT v1 = v0 + a;
-                        carry += wave_last_u32(incl);
-                        if (vec_ok) {
-                            store_nt8(q, v0, v1);
-                        } else {
-                            q[0] = v0;
-                            q[1] = v1;
+                            const UT a = ua + (UT)md;
+                            const UT pair = a + ub + (UT)md;
+                            const UT incl = wave_scan_u32(pair);
+                            const UT v0 = carry + (incl - pair);
+                            const UT v1 = v0 + a;
+                            carry += wave_last_u32(incl);
+                            if (vec_ok) {
+                                store_nt8(q, v0, v1);
+                            } else {
+                                q[0] = v0;
+                                q[1] = v1;
+                            }
                         }
                     }
                     o = next;
-                    p0 += 128u;
+                    p0 += kBlockValues;
                 }
             }
             if (!(!st.finished && (tail || o + (uint32_t)kDwBlockMax <= (uint32_t)kDwChunk))) break;
