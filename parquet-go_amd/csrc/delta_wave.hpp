@@ -500,7 +500,7 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
         const int64_t left = len - c0;
         const uint32_t lim = left > (int64_t)kDwChunk ? (uint32_t)kDwChunk : (left < 0 ? 0u : (uint32_t)left);
         while (true) {
-            if constexpr (!OFFS) {
+            {
                 // The blocks in the middle of a page — whole, plain, more values wanted behind them —
                 // in a loop of their own with one way out: header walk and decode back to back, no
                 // state handed from one to the other.  Whatever ends it (the page's last block, a
@@ -573,9 +573,19 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
                             const UT a = ua + (UT)md;
                             const UT pair = a + ub + (UT)md;
                             const UT incl = wave_scan_u32(pair);
-                            const UT v0 = carry + (incl - pair);
-                            const UT v1 = v0 + a;
+                            UT v0 = carry + (incl - pair);
+                            UT v1 = v0 + a;
                             carry += wave_last_u32(incl);
+                            if constexpr (OFFS) {
+                                // the values are lengths: what is stored is the sum of those in front
+                                const uint32_t l0 = v0, both = v0 + v1;
+                                const uint32_t oincl = wave_scan_u32(both);
+                                wo->big |= __builtin_amdgcn_ballot_w64((v0 | v1) >= (1u << 24)) != 0ull ? 1u : 0u;
+                                v0 = wo->sum + (oincl - both);
+                                v1 = v0 + l0;
+                                wo->sum += wave_last_u32(oincl);
+                                wo->big |= wo->sum >> 31;
+                            }
                             if (vec_ok) {
                                 store_nt8(q, v0, v1);
                             } else {

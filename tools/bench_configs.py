@@ -128,11 +128,11 @@ def bench_bitunpack(ctx, stream, bits, widths, enc_bytes, out_cap=2 << 30):
         del t_out
 
 
-def bench_nested(ctx, stream, pages, n):
+def bench_nested(ctx, stream, pages, n, distinct=100):
     rng = np.random.default_rng(5)
     d = synth.splitmix64(7, 4096).astype(np.uint32).view(np.int32)
     streams, nn = [], []
-    distinct = min(pages, 100)
+    distinct = min(pages, distinct)
     for p in range(distinct):
         rep = (rng.random(n) >= 0.25).astype(np.int64)
         deff = np.where(rng.random(n) < 0.8, 3, rng.integers(0, 3, size=n))
@@ -388,6 +388,8 @@ def main():
         bench_bitunpack(ctx, stream, 64, list(range(1, 65)), 1 << 30, out_cap=16 << 30)
     if want("c4"):
         bench_nested(ctx, stream, args.pages, 20000)
+    if args.only and want("c4big"):   # the large-page variant: 500 pages x 1 M slots (10 distinct pages)
+        bench_nested(ctx, stream, 500, 1_000_000, distinct=10)
     if want("c2x"):
         for w in (4, 8, 24, 30, 32):
             bench_delta(ctx, stream, args.pages, 20000, 64, w)
