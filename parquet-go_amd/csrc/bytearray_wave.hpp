@@ -161,10 +161,10 @@ __device__ __forceinline__ ByteArrayResult delta_length_ba_wave(uint32_t *window
             const uint32_t total = fr.total, m = min(n, total);
             const uint64_t avail = (uint64_t)len - fr.consumed;  // bytes behind the lengths
             if (lane == 0) area[total] = wo.sum;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             auto off = [&](uint32_t i) -> uint32_t {
-                return uni(__hip_atomic_load(area + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                return uni(__hip_atomic_load(area + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             };
             uint32_t done = m;
             uint64_t bytes = off(m);
@@ -200,8 +200,8 @@ __device__ __forceinline__ ByteArrayResult delta_length_ba_wave(uint32_t *window
     }
     const uint32_t total = lr.total;
     // the lengths went out as plain and non-temporal stores: make them visible to the loads below
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     const uint64_t avail = (uint64_t)len - lr.consumed;  // bytes behind the lengths
     const uint32_t m = min(n, total);
@@ -214,7 +214,7 @@ __device__ __forceinline__ ByteArrayResult delta_length_ba_wave(uint32_t *window
     auto load_lens = [&](uint32_t i0, int32_t *c) {
 #pragma unroll
         for (uint32_t k = 0; k < kPer; ++k)
-            c[k] = i0 + k < m ? (int32_t)__hip_atomic_load(area + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            c[k] = i0 + k < m ? (int32_t)__hip_atomic_load(area + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
     };
     int32_t cur[kPer], next[kPer];
     load_lens(kPer * (uint32_t)lane, cur);
@@ -347,8 +347,8 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
         res.consumed = init_consumed;
         return res;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
     // ---- pass A: lengths -> offsets, and the first value DecodeValues fails at ----
     const uint32_t total = ls.total;
@@ -358,7 +358,7 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
     uint32_t prev_carry = 0, done = 0;
     int32_t status = PQ_OK;
     auto load_word = [&](const uint32_t *base, uint32_t i) -> int32_t {
-        return i < m ? (int32_t)__hip_atomic_load(base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        return i < m ? (int32_t)__hip_atomic_load(base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
     };
     int32_t cur_s = load_word(area, (uint32_t)lane);
     res.consumed = init_consumed;
@@ -427,8 +427,8 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
     // in front of the batch, which the output window still holds), and whole 16-byte pieces of the
     // output window go to memory.  The window is circular, indexed by the low bits of the output
     // ADDRESS, so a 16-byte piece of memory is a 16-byte piece of LDS and nothing is ever moved.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const uint8_t *SUF = S + init_consumed;
     uint8_t *obuf = reinterpret_cast<uint8_t *>(window);  // the lengths are done with the window
     uint8_t *sbuf = obuf + kBaOutWin;
@@ -444,8 +444,8 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
     auto load_lens = [&](uint32_t b, uint32_t &a0, uint32_t &a1, int32_t &ap) {
         const uint32_t i = b + (uint32_t)lane;
         const bool in = i < done;
-        a0 = in ? __hip_atomic_load(area + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        a1 = in ? __hip_atomic_load(area + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        a0 = in ? __hip_atomic_load(area + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+        a1 = in ? __hip_atomic_load(area + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
         ap = in ? (int32_t)P[i] : 0;
     };
     uint32_t o0, o1;

@@ -67,6 +67,8 @@ struct ChunkSlot {
     size_t off_levels = 0, off_results = 0;
 };
 
+constexpr int kGroups = 6;  // kernel groups of a plan
+
 struct pq_plan {
     pq_ctx *ctx = nullptr;
     size_t n = 0;
@@ -76,9 +78,10 @@ struct pq_plan {
     pq_page_result *d_results = nullptr;
     uint32_t *d_flags = nullptr; // [0], [32], [64]: sweep wake-up words (delta32, delta64, data pages)
     uint32_t epoch = 0;          // bumped every run; a flag word equal to it is "raised"
-    // descriptor ids grouped by kernel: [stream | delta32 | delta64 | data pages]
-    uint32_t count[4] = {0, 0, 0, 0};
-    uint32_t first[4] = {0, 0, 0, 0};
+    // descriptor ids grouped by kernel:
+    // [stream | delta32 | delta64 | data pages | DELTA_LENGTH_BYTE_ARRAY | DELTA_BYTE_ARRAY]
+    uint32_t count[kGroups] = {0, 0, 0, 0, 0, 0};
+    uint32_t first[kGroups] = {0, 0, 0, 0, 0, 0};
     uint64_t src_need = 0, values_need = 0, levels_need = 0, dict_need = 0;
     uint32_t dict_lds_bytes = 0;
     // set when every dictionary user reads one and the same dictionary that fits LDS
@@ -113,7 +116,7 @@ bool hip_ok(pq_ctx *ctx, hipError_t e, const char *what)
         if (!hip_ok((ctx), (call), #call)) return PQ_ERR_HIP; \
     } while (0)
 
-int group_of(uint32_t kind)
+int kind_group(uint32_t kind)
 {
     switch (kind) {
     case PQ_KIND_HYBRID:
@@ -121,9 +124,9 @@ int group_of(uint32_t kind)
     case PQ_KIND_LEVELS:
     case PQ_KIND_PLAIN:
     case PQ_KIND_BOOL_PLAIN:
-    case PQ_KIND_BOOL_RLE:
-    case PQ_KIND_DELTA_LENGTH_BA:
-    case PQ_KIND_DELTA_BA: return 0;
+    case PQ_KIND_BOOL_RLE: return 0;
+    case PQ_KIND_DELTA_LENGTH_BA: return 4;
+    case PQ_KIND_DELTA_BA: return 5;
     case PQ_KIND_DELTA32: return 1;
     case PQ_KIND_DELTA64: return 2;
     case PQ_KIND_PAGE_V1:
@@ -138,6 +141,16 @@ uint32_t byte_array_kind(const pq_page_desc &d)
     const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
     const uint32_t k = page ? d.value_kind : d.kind;
     return k == PQ_KIND_DELTA_LENGTH_BA || k == PQ_KIND_DELTA_BA ? k : 0u;
+}
+
+// The kernel group of a descriptor.  Byte arrays have kernels of their own (bytearray.hip), also
+// as the values of a flat column's page whose constant levels are not written out.
+int group_of(const pq_page_desc &d)
+{
+    const int g = kind_group(d.kind);
+    if (g == 3 && d.max_rep == 0 && (d.flags & PQ_FLAG_NO_LEVEL_OUTPUT) != 0)
+        if (const uint32_t ba = byte_array_kind(d)) return kind_group(ba);
+    return g;
 }
 
 // Bytes per output value of a descriptor (0 = it writes no fixed-width value output).
@@ -159,7 +172,7 @@ uint32_t value_size(const pq_page_desc &d)
 
 int validate(const pq_page_desc &d)
 {
-    if (group_of(d.kind) < 0) return PQ_ERR_BAD_ARGUMENT;
+    if (kind_group(d.kind) < 0) return PQ_ERR_BAD_ARGUMENT;
     if (d.n_values > 0x7fffffffu) return PQ_ERR_BAD_ARGUMENT; // counts are int32 in the reference
     if (d.src_len > 0x7fffffffffffull) return PQ_ERR_BAD_ARGUMENT;
     const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
@@ -432,7 +445,7 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
 {
     if (!ctx || !out || (n_pages && !descs) || n_pages > 0x7fffffffu) return PQ_ERR_BAD_ARGUMENT;
     *out = nullptr;
-    std::vector<uint32_t> ids[4];
+    std::vector<uint32_t> ids[kGroups];
     pq_plan *plan = new (std::nothrow) pq_plan;
     if (!plan) return PQ_ERR_BAD_ARGUMENT;
     plan->ctx = ctx;
@@ -447,7 +460,7 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
             delete plan;
             return st;
         }
-        ids[group_of(d.kind)].push_back((uint32_t)i);
+        ids[group_of(d)].push_back((uint32_t)i);
         plan->src_need = std::max(plan->src_need, d.src_off + d.src_len);
         if ((d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2) &&
             (d.value_kind == PQ_KIND_DELTA32 || d.value_kind == PQ_KIND_DELTA64))
@@ -502,7 +515,7 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
     };
     std::vector<uint8_t> bucket(n_pages);
     for (size_t i = 0; i < n_pages; ++i) bucket[i] = (uint8_t)work_bucket((uint32_t)i);
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < kGroups; ++g) {
         bool mixed = false;
         for (uint32_t i : ids[g]) mixed = mixed || bucket[i] != bucket[ids[g][0]];
         if (mixed)
@@ -579,7 +592,7 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
     }
     std::vector<uint32_t> all;
     all.reserve(n_pages);
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < kGroups; ++g) {
         plan->first[g] = (uint32_t)all.size();
         plan->count[g] = (uint32_t)ids[g].size();
         all.insert(all.end(), ids[g].begin(), ids[g].end());
@@ -747,6 +760,10 @@ int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_valu
     PQ_HIP(ctx, pq::launch_data_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[3],
                                       plan->count[3], buf, plan->d_results, plan->dict_lds_bytes, wl,
                                       plan->d_flags + 64, plan->epoch));
+    PQ_HIP(ctx, pq::launch_byte_arrays(ctx->stream, PQ_KIND_DELTA_LENGTH_BA, plan->d_descs, plan->d_ids + plan->first[4],
+                                       plan->count[4], buf, plan->d_results));
+    PQ_HIP(ctx, pq::launch_byte_arrays(ctx->stream, PQ_KIND_DELTA_BA, plan->d_descs, plan->d_ids + plan->first[5],
+                                       plan->count[5], buf, plan->d_results));
     // groups 1..3 are contiguous in d_ids; pages whose delta layout the tiled kernels
     // declined (and did not finish themselves) are completed one lane per page
     if (serial32 || serial64 || plan->has_delta_page)

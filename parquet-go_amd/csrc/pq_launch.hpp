@@ -51,6 +51,10 @@ hipError_t launch_data_pages(hipStream_t s, const pq_page_desc *d_descs, const u
 
 // Finishes, one lane per page, the delta descriptors among ids[0..count) that the
 // tiled kernels marked as needing the serial path; a no-op for all others.
+// bytearray.hip: kind = PQ_KIND_DELTA_LENGTH_BA or PQ_KIND_DELTA_BA; the ids name bare streams of that
+// kind or flat-column pages (max_rep == 0, PQ_FLAG_NO_LEVEL_OUTPUT) whose values are of that kind
+hipError_t launch_byte_arrays(hipStream_t s, uint32_t kind, const pq_page_desc *d_descs, const uint32_t *d_ids,
+                              uint32_t count, PageBuffers buf, pq_page_result *d_results);
 hipError_t launch_delta_serial(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
                                uint32_t count, PageBuffers buf, pq_page_result *d_results);
 
