@@ -427,6 +427,106 @@ __device__ __forceinline__ void wave_decode_tile(const uint32_t *lds, const Wave
     if (!CLIPPED || p + 1u < clip) dst[p + 1u] = v1;
 }
 
+// Two blocks of 4-byte values in the 128 / 4 layout at a time, entirely on the vector unit: lanes
+// 0..31 take the first block, lanes 32..63 the one behind it, four adjacent values each, so that
+// one prefix sum and one 16-byte store per lane serve 256 values.  (Not for 8-byte values: four
+// adjacent ones per lane make every store instruction write half of each 64-byte line, which
+// halves the rate the stores go out at, and at one 16-byte store per two values that decode is
+// within a few percent of what the memory system takes anyway.)  The first header is
+// parsed by every lane as far as the place the second one starts at; then each half parses its
+// own header in full (minDelta of 1..4 varint bytes, widths, where the block ends) and unpacks.
+// Like the single-block loop behind it, this one only takes blocks in the middle of a page that
+// lie whole inside the window, and leaves everything else where it is: it returns at the first
+// pair that is not of that kind, having advanced o (window offset of the next header), p0
+// (position of its first value), carry (that value) and *wo.  stop_rel: a header at or behind
+// this window offset is not to be decoded (segments), else 0x7fffffff.
+template <typename UT, bool OFFS>
+__device__ __forceinline__ void delta_pair_loop(const uint32_t *lds, UT *dst, uint32_t &o, uint32_t &p0, UT &carry,
+                                                uint32_t need, uint32_t lim, uint32_t o_max, int32_t stop_rel,
+                                                WaveOffsets *wo, int lane)
+{
+    static_assert(sizeof(UT) == 4, "four adjacent values per lane go out in one 16-byte store");
+    const bool upper = lane >= 32;
+    const uint32_t j = (uint32_t)lane & 31u;
+    const uint32_t sh8 = (j >> 3) * 8u;  // 8 * the miniblock of this lane's 4 values
+    const uint32_t k4 = 4u * (j & 7u);   // index of the first of them inside the miniblock
+    while (o <= o_max && p0 + 256u < need && (int32_t)o < stop_rel) {
+        // where the second header starts: the first one's varint length and the sum of its widths
+        uint32_t next_a;
+        {
+            const uint32_t k = o >> 2;
+            const uint32_t d0 = lds[k], d1 = lds[k + 1], d2 = lds[k + 2];
+            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, o * 8u);
+            const uint32_t mid = __builtin_amdgcn_alignbit(d2, d1, o * 8u);
+            const uint32_t end = ~lo & 0x80808080u;
+            const uint32_t vl = ((uint32_t)__builtin_ctz(end | 0x80000000u) + 1u) >> 3;
+            const uint32_t widths = (uint32_t)(((((uint64_t)mid) << 32) | lo) >> (8u * vl));
+            next_a = o + vl + 4u + 4u * __builtin_amdgcn_sad_u8(widths, 0u, 0u);
+        }
+        // a first header that is not a plain one sends the second half anywhere: keep its reads inside the window
+        const uint32_t ho = upper ? min(next_a, (uint32_t)kDwChunk) : o;
+        const uint32_t k = ho >> 2;
+        const uint32_t d0 = lds[k], d1 = lds[k + 1], d2 = lds[k + 2];
+        const uint32_t hdr_lo = __builtin_amdgcn_alignbit(d1, d0, ho * 8u);
+        const uint32_t mid = __builtin_amdgcn_alignbit(d2, d1, ho * 8u);
+        const uint32_t end = ~hdr_lo & 0x80808080u;
+        const uint32_t vl = ((uint32_t)__builtin_ctz(end | 0x80000000u) + 1u) >> 3;  // 1..4
+        const uint32_t widths = (uint32_t)(((((uint64_t)mid) << 32) | hdr_lo) >> (8u * vl));
+        const uint32_t data = ho + vl + 4u;
+        const uint32_t next = data + 4u * __builtin_amdgcn_sad_u8(widths, 0u, 0u);
+        // minDelta of five bytes and more, a width above 32, a block that is not all in the window, a
+        // second block at or behind the stop
+        const bool bad = end == 0u || ((((widths & 0x7f7f7f7fu) + 0x5f5f5f5fu) | widths) & 0x80808080u) != 0u || next > lim ||
+                         (upper && (int32_t)next_a >= stop_rel);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0ull) break;
+
+        // minDelta from its raw varint
+        const uint32_t mv = hdr_lo & (0xffffffffu >> (32u - 8u * vl));
+        const uint32_t mx = (mv & 0x7fu) | ((mv >> 1) & 0x3f80u) | ((mv >> 2) & 0x1fc000u) | ((mv >> 3) & 0xfe00000u);
+        const int32_t md = (int32_t)(mx >> 1) ^ -(int32_t)(mx & 1u);
+        // the four deltas: byte m of `sums` = the widths of miniblocks 0..m together (at most 128)
+        const uint32_t w = __builtin_amdgcn_ubfe(widths, sh8, 8u);
+        const uint32_t sum2 = widths + (widths << 8);
+        const uint32_t sums = sum2 + (sum2 << 16);
+        const uint32_t pre = __builtin_amdgcn_ubfe(sums << 8, sh8, 8u);
+        const uint32_t bit = data * 8u + (pre << 5) + __umul24(k4, w);
+        const uint32_t m = (uint32_t)(1ull << w) - 1u;  // w == 32 -> 0xffffffff, w == 0 -> 0
+        uint32_t u[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const uint32_t bq = bit + q * w;
+            const uint32_t i = bq >> 5;
+            u[q] = __builtin_amdgcn_alignbit(lds[i + 1], lds[i], bq) & m;
+        }
+        UT v[4];
+        {
+            const UT s1 = u[0] + (UT)md, s2 = s1 + u[1] + (UT)md, s3 = s2 + u[2] + (UT)md, s4 = s3 + u[3] + (UT)md;
+            const UT incl = wave_scan_u32(s4);
+            v[0] = carry + (incl - s4);
+            v[1] = v[0] + s1;
+            v[2] = v[0] + s2;
+            v[3] = v[0] + s3;
+            carry += wave_last_u32(incl);
+            if constexpr (OFFS) {
+                // the values are lengths: what is stored is the sum of those in front.  256 lengths
+                // below 2^23 on top of a total below 2^31 cannot wrap.
+                const uint32_t t1 = v[0], t2 = t1 + v[1], t3 = t2 + v[2], t4 = t3 + v[3];
+                const uint32_t oincl = wave_scan_u32(t4);
+                wo->big |= __builtin_amdgcn_ballot_w64((v[0] | v[1] | v[2] | v[3]) >= (1u << 23)) != 0ull ? 1u : 0u;
+                v[0] = wo->sum + (oincl - t4);
+                v[1] = v[0] + t1;
+                v[2] = v[0] + t2;
+                v[3] = v[0] + t3;
+                wo->sum += wave_last_u32(oincl);
+                wo->big |= wo->sum >> 31;
+            }
+            store_nt16(dst + p0 + 4u * (uint32_t)lane, v[0], v[1], v[2], v[3]);
+        }
+        o = (uint32_t)__builtin_amdgcn_readlane((int)next, 63);
+        p0 += 256u;
+    }
+}
+
 struct WaveDeltaResult {
     int32_t status; // PQ_*, or kNeedGeneric when the layout is not 128 / 4
     uint32_t n_decoded;
@@ -482,6 +582,7 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
         return res;
     }
 
+    const bool vec16 = (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;  // 4 x int32 or 2 x int64 in one store
     WaveLane ln;
     ln.sh8 = ((2u * (uint32_t)lane) >> LG) * 8u;
     ln.k2 = (2u * (uint32_t)lane) & ((1u << LG) - 1u);
@@ -512,6 +613,12 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
                 int32_t stop_rel = 0x7fffffff;
                 if constexpr (SEG) {
                     if (seg_stop >= 0 && seg_stop - c0 < (int64_t)0x7fffffff) stop_rel = (int32_t)(seg_stop - c0);
+                }
+                if constexpr (LG == 5u && sizeof(UT) == 4) {
+                    // pairs of blocks first; what ends the pair loop is one of the single-block loop's cases
+                    if (vec16)
+                        delta_pair_loop<UT, OFFS>(lds, dst, o, p0, carry, st.need, lim,
+                                                  tail ? 0x7fffffffu : (uint32_t)(kDwChunk - 2 * kDwBlockMax), stop_rel, wo, lane);
                 }
                 while (o <= o_max && p0 + kBlockValues < st.need && (int32_t)o < stop_rel && (LG == 5u || blk.half == 0u)) {
                     const uint32_t k = o >> 2, sh = (o & 3u) * 8u;

@@ -126,23 +126,19 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x)
     return x;
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint64_t dpp0_64(uint64_t x)
-{
-    uint32_t lo = dpp0<CTRL, ROW_MASK>((uint32_t)x);
-    uint32_t hi = dpp0<CTRL, ROW_MASK>((uint32_t)(x >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-
+// Inclusive 64-bit prefix sum over the wave as two 32-bit ones.  The low words are summed
+// modulo 2^32; adding lane j's low word wrapped exactly when the running sum came out below that
+// word (one addition wraps at most once), so the carries into the high word up to lane j are the
+// wraps of lanes 0..j: a ballot and a bit count instead of carrying through every DPP step.
 __device__ __forceinline__ uint64_t wave_scan_u64(uint64_t x)
 {
-    x += dpp0_64<0x111, 0xf>(x);
-    x += dpp0_64<0x112, 0xf>(x);
-    x += dpp0_64<0x114, 0xf>(x);
-    x += dpp0_64<0x118, 0xf>(x);
-    x += dpp0_64<0x142, 0xa>(x);
-    x += dpp0_64<0x143, 0xc>(x);
-    return x;
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    const uint32_t slo = wave_scan_u32(lo);
+    const uint32_t shi = wave_scan_u32(hi);
+    const bool wrapped = slo < lo;
+    const uint64_t wraps = __builtin_amdgcn_ballot_w64(wrapped);
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(wraps >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wraps, 0u));
+    return ((uint64_t)(shi + below + (wrapped ? 1u : 0u)) << 32) | slo;
 }
 
 __device__ __forceinline__ uint32_t wave_last_u32(uint32_t x) { return __builtin_amdgcn_readlane((int)x, 63); }
