@@ -164,6 +164,46 @@ def test_wrong_guesses_fall_back_to_the_chain(ctx, bits):
     _run(ctx, cases, bits, 8192, seed=5)
 
 
+def _mixed_width_values(rng, n, dt):
+    """Deltas whose miniblocks (32 values) differ in width, 0 and 32 bits included, under block
+    minimums whose zig-zag varints take one to five bytes."""
+    n -= 1    # the first value stands in the stream header; block k holds deltas 128 k ..
+    deltas = np.zeros(n, dtype=np.int64)
+    for b0 in range(0, n, 128):
+        md = int(rng.choice([0, -3, 60, -5000, 70000, -(1 << 22), 1 << 26, -(1 << 27), (1 << 30) - 7, -(1 << 30)]))
+        for m0 in range(b0, min(b0 + 128, n), 32):
+            w = int(rng.choice([0, 1, 5, 12, 17, 22, 23, 24, 31, 32]))
+            k = min(32, n - m0)
+            noise = rng.integers(0, 1 << w, size=k, dtype=np.int64) if w else np.zeros(k, np.int64)
+            if w and m0 == b0:
+                noise[0] = 0    # the block's minimum is md itself
+            deltas[m0:m0 + k] = md + noise
+    with np.errstate(over="ignore"):
+        v = np.cumsum(np.concatenate([[int(rng.integers(-2**31, 2**31))], deltas]))
+    return v.astype(dt)    # int64 sums wrap the way the decoder's do; the low 32 bits are the int32 sums
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_blocks_of_mixed_widths_and_long_minimums(ctx, bits):
+    """What the two-blocks-at-a-time loop of the 4-byte decode parses itself: per-miniblock widths
+    from 0 to 32 inside one block, minDelta varints of 1..4 bytes (and of 5, which it hands on),
+    pages that end after an odd or even number of blocks, cut anywhere in the last two pairs."""
+    rng = np.random.default_rng(170 + bits)
+    dt = np.int32 if bits == 32 else np.int64
+    cases = []
+    for n in (258, 386, 514, 1000, 128 * 41 + 7, 128 * 64 + 2, 40000):
+        vals = _mixed_width_values(rng, n, dt)
+        stream = synth.delta_encode(vals, bits)
+        want = (O.delta_decode32 if bits == 32 else O.delta_decode64)(stream, n)
+        assert want["status"] == O.OK and np.array_equal(want["values"], vals)
+        for pull in sorted({n, n - 1, n - 127, n - 129, n // 2, n + 3}):
+            cases.append(_case(bits, stream, pull))
+        for cut in rng.integers(max(stream.size - 1500, 0), stream.size, size=12):
+            cases.append(_case(bits, stream[: int(cut)].copy(), n))
+    _run(ctx, cases, bits, 2048, seed=17)
+    _run(ctx, cases, bits, 4096, seed=18)
+
+
 def test_large_and_small_pages_in_one_plan(ctx):
     rng = np.random.default_rng(9)
     cases = []
