@@ -459,6 +459,321 @@ __global__ __launch_bounds__(kAsmWG) void entries_write_kernel(const int32_t *__
     }
 }
 
+// ---- the same in ONE launch ---------------------------------------------------------------------
+// Summary, chaining and writing in one pass over the levels: a workgroup takes its four tiles'
+// ballots (kept in registers), publishes the group's summary, finds the state that enters the
+// group by looking back over the groups in front of it, publishes the state that leaves it, and
+// writes its entries.  A group's two records are one 64-bit word each, payload and presence bit
+// together, stored and loaded with relaxed agent-scope atomics: no fence, nothing to order.
+//   agg[g]: bit 0 present | V_out(0), V_out(1) | entries(0), entries(1), values(0), values(1), 14 bits each
+//   pre[g]: bit 0 present | V that leaves the group | entries in front of the next group, 30 bits | values, 30 bits
+// Workgroups start in the order of their index, so the groups a look-back waits for are running
+// or done.  n < 2^30 (the 30-bit counts); agg and pre must be zero on entry.
+constexpr uint64_t kOnePassMaxN = 1ull << 30;
+constexpr int kOnePassWG = 256;  // 4 tiles = 8192 positions per group: a group's counts fit 14 bits
+
+__device__ __forceinline__ uint64_t agg_pack(uint32_t v, uint32_t h0, uint32_t h1, uint32_t c0, uint32_t c1)
+{
+    return 1ull | ((uint64_t)v << 1) | ((uint64_t)h0 << 3) | ((uint64_t)h1 << 17) | ((uint64_t)c0 << 31) | ((uint64_t)c1 << 45);
+}
+
+__device__ __forceinline__ uint64_t pre_pack(uint32_t v, uint32_t k, uint32_t vb)
+{
+    return 1ull | ((uint64_t)v << 1) | ((uint64_t)k << 2) | ((uint64_t)vb << 32);
+}
+
+// The state {V, entries, values} that enters group g.  Called by one whole wave.  Lane i looks at
+// group j - i; the nearest group whose leaving state is known ends the search, the summaries of
+// the groups between it and g are chained as the steps of a tile are: their V bits are a carry
+// chain (one addition), and each then adds its counts under the V that enters it.
+__device__ __forceinline__ void entries_look_back(const uint64_t *agg, const uint64_t *pre, uint64_t g, int lane,
+                                                  uint32_t &vin, uint32_t &K, uint32_t &vb)
+{
+    AsmFn behind = asm_identity();  // the groups already passed over (nearer to g), as one function
+    int64_t j = (int64_t)g - 1;
+    while (true) {
+        const int64_t idx = j - lane;
+        uint64_t a = 0, p = 0;
+        uint64_t known, waiting;
+        // Lanes look only as far back as it takes: 8 groups at first, all 64 when none of those
+        // knows its leaving state (every look is a memory transaction per lane that no cache serves).
+        uint32_t width = 8;
+        do {
+            if (idx < 0) {
+                p = pre_pack(0u, 0u, 0u);  // in front of the first group: nothing
+            } else if ((uint32_t)lane < width) {
+                if ((p & 1ull) == 0ull) p = __hip_atomic_load(pre + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (((p | a) & 1ull) == 0ull) a = __hip_atomic_load(agg + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            known = __builtin_amdgcn_ballot_w64((p & 1ull) != 0ull);
+            // every group nearer than the nearest known state has to show its summary
+            const uint64_t nearer = known ? ((known & (0ull - known)) - 1ull) : ~0ull;
+            waiting = __builtin_amdgcn_ballot_w64(((p | a) & 1ull) == 0ull) & nearer;
+            if (known == 0ull && width < (uint32_t)kWave && (waiting & ((1ull << width) - 1ull)) == 0ull)
+                width = kWave;  // the near ones have all shown their summaries and none its state
+            else if (waiting != 0ull)
+                __builtin_amdgcn_s_sleep(1);
+        } while (waiting != 0ull);
+        const uint32_t fp = known ? (uint32_t)__builtin_ctzll(known) : (uint32_t)kWave;  // lanes below fp: summaries
+        const bool mine = (uint32_t)lane < fp;
+        const uint32_t av = mine ? (uint32_t)(a >> 1) & 3u : 2u;  // identity elsewhere
+        const uint32_t h0 = mine ? (uint32_t)(a >> 3) & 0x3fffu : 0u, h1 = mine ? (uint32_t)(a >> 17) & 0x3fffu : 0u;
+        const uint32_t c0 = mine ? (uint32_t)(a >> 31) & 0x3fffu : 0u, c1 = mine ? (uint32_t)(a >> 45) & 0x3fffu : 0u;
+        // chain order is from the farthest group (highest lane) to the nearest (lane 0): reverse the ballots
+        const uint64_t G = __builtin_bitreverse64(__builtin_amdgcn_ballot_w64((av & 1u) != 0u));
+        const uint64_t A = __builtin_bitreverse64(__builtin_amdgcn_ballot_w64((av & 2u) != 0u));
+        const uint32_t bit = 63u - (uint32_t)lane;  // this lane's place in the chain
+        if (known != 0ull) {
+            const uint64_t pw = readlane_u64(p, fp);
+            const uint32_t v0 = (uint32_t)(pw >> 1) & 1u;
+            const uint64_t x = (A + G + v0) ^ A ^ G;  // bit b: the V that enters chain place b (lanes >= fp are identities)
+            const unsigned __int128 s = (unsigned __int128)A + G + v0;
+            const uint32_t vout = (uint32_t)(s >> 64);
+            const uint32_t my_in = (uint32_t)(x >> bit) & 1u;
+            const uint32_t hs = wave_sum_u32(my_in ? h1 : h0), cs = wave_sum_u32(my_in ? c1 : c0);
+            uint32_t v = vout, k = ((uint32_t)(pw >> 2) & 0x3fffffffu) + hs, c = ((uint32_t)(pw >> 32) & 0x3fffffffu) + cs;
+            // then the groups passed over in earlier rounds
+            k += behind.h[v];
+            c += behind.c[v];
+            v = (behind.v >> v) & 1u;
+            vin = v;
+            K = k;
+            vb = c;
+            return;
+        }
+        // no known state among these 64: they become one function, in front of `behind`
+        AsmFn r;
+        r.v = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 2u; ++k) {
+            const uint64_t x = (A + G + k) ^ A ^ G;
+            const unsigned __int128 s = (unsigned __int128)A + G + k;
+            const uint32_t my_in = (uint32_t)(x >> bit) & 1u;
+            r.h[k] = wave_sum_u32(my_in ? h1 : h0);
+            r.c[k] = wave_sum_u32(my_in ? c1 : c0);
+            r.v |= (uint32_t)(s >> 64) << k;
+        }
+        behind = asm_then(r, behind.v, behind.h[0], behind.h[1], behind.c[0], behind.c[1]);
+        j -= kWave;
+    }
+}
+
+template <int WG>
+__global__ __launch_bounds__(WG) void entries_onepass_kernel(const int32_t *__restrict__ def,
+                                                                 const int32_t *__restrict__ rep, uint64_t n,
+                                                                 int32_t max_def, int32_t max_rep, int repeated,
+                                                                 uint64_t *agg, uint64_t *pre, uint64_t groups,
+                                                                 uint32_t *__restrict__ offsets,
+                                                                 uint32_t *__restrict__ validity,
+                                                                 int32_t *__restrict__ entry_def,
+                                                                 pq_entries_result *__restrict__ result)
+{
+    __shared__ uint32_t wsum[WG / kWave][5];
+    __shared__ uint32_t gstate[3];  // V, entries, values that enter the group
+    __shared__ __attribute__((aligned(16))) uint32_t vbytes[WG / kWave][kAsmVbWords];
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint64_t tile = (uint64_t)blockIdx.x * (WG / kWave) + wave;
+    const uint64_t base = tile * kAsmTile;
+    const uint32_t steps = base >= n ? 0u : (uint32_t)min((uint64_t)kAsmSteps, (n - base + kWave - 1) / kWave);
+
+    // ---- ballots: lane s keeps those of step s ----
+    uint64_t my_c = 0, my_d = 0;
+    // The definition levels are wanted once more, for the entries without a value.  A whole tile
+    // keeps them, a byte each (step s in byte s & 3 of dkeep[s >> 2]), unless one of them does
+    // not fit a byte; the tile then reads them again, like the tile at the end of the column.
+    uint32_t dkeep[kAsmSteps / 4];
+#pragma unroll
+    for (int k = 0; k < kAsmSteps / 4; ++k) dkeep[k] = 0;
+    uint32_t dbits = 0xffffffffu;  // all the levels of this lane or-ed together
+    if (steps == (uint32_t)kAsmSteps && base + kAsmTile <= n) {
+        dbits = 0;
+        const int32_t *dp = def + base + lane;
+        const int32_t *rp = repeated ? rep + base + lane : dp;
+#pragma unroll
+        for (uint32_t s0 = 0; s0 < (uint32_t)kAsmSteps; s0 += 16) {
+            int32_t dl[16], rl[16];
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) dl[j] = dp[(s0 + j) * kWave];
+            if (repeated) {
+#pragma unroll
+                for (uint32_t j = 0; j < 16; ++j) rl[j] = rp[(s0 + j) * kWave];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) {
+                const uint64_t D = __builtin_amdgcn_ballot_w64(dl[j] >= max_def);
+                const uint64_t C = repeated ? __builtin_amdgcn_ballot_w64(rl[j] >= max_rep) : 0ull;
+                if ((uint32_t)lane == s0 + j) {
+                    my_c = C;
+                    my_d = D;
+                }
+                dbits |= (uint32_t)dl[j];
+                dkeep[(s0 + j) >> 2] |= ((uint32_t)dl[j] & 0xffu) << (8u * ((s0 + j) & 3u));
+            }
+        }
+    } else {
+        for (uint32_t s0 = 0; s0 < steps; s0 += 8) {
+            StepMasks m[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j)
+                m[j] = asm_masks(def, rep, base + (uint64_t)(s0 + j) * kWave + lane, n, max_def, max_rep, repeated != 0);
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j)
+                if ((uint32_t)lane == s0 + j) {
+                    my_c = m[j].c;
+                    my_d = m[j].d;
+                }
+        }
+    }
+    // positions of this lane's step that exist (none for the lanes past the tile's last step)
+    const uint64_t left = (uint32_t)lane < steps ? n - base - (uint64_t)lane * kWave : 0ull;
+    const uint64_t my_valid = left >= 64 ? ~0ull : (1ull << left) - 1ull;
+
+    // ---- the tile's summary for either V that may enter it ----
+    const BlockChain bc = asm_block_chain(my_c, my_d);
+    {
+        uint32_t hs[2], ns[2], vouts[2];
+#pragma unroll
+        for (uint32_t k = 0; k < 2; ++k) {
+            const uint64_t xb = asm_chain_in(bc, k);
+            uint64_t x, v;
+            uint32_t vo;
+            asm_step(my_c, my_d, (uint32_t)(xb >> lane) & 1u, x, v, vo);
+            hs[k] = wave_sum_u32((uint32_t)__builtin_popcountll(~(my_c & x) & my_valid));
+            ns[k] = wave_sum_u32((uint32_t)__builtin_popcountll(v & my_valid));
+            vouts[k] = (uint32_t)(xb >> steps) & 1u;
+        }
+        if (lane == 0) {
+            wsum[wave][0] = vouts[0] | (vouts[1] << 1);
+            wsum[wave][1] = hs[0];
+            wsum[wave][2] = hs[1];
+            wsum[wave][3] = ns[0];
+            wsum[wave][4] = ns[1];
+        }
+    }
+    __syncthreads();
+
+    // ---- the group's summary out, the state that enters it in ----
+    if (wave == 0u) {
+        uint32_t v[2] = {0, 1}, h[2] = {0, 0}, c[2] = {0, 0};
+        for (int w = 0; w < WG / kWave; ++w)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t vi = v[k];
+                h[k] += wsum[w][1 + vi];
+                c[k] += wsum[w][3 + vi];
+                v[k] = (wsum[w][0] >> vi) & 1u;
+            }
+        const uint64_t g = blockIdx.x;
+        if (lane == 0)
+            __hip_atomic_store(agg + g, agg_pack(v[0] | (v[1] << 1), h[0], h[1], c[0], c[1]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t vin = 0, K = 0, vb = 0;
+        entries_look_back(agg, pre, g, lane, vin, K, vb);
+        const uint32_t vout = v[vin], k_out = K + h[vin], vb_out = vb + c[vin];
+        if (lane == 0) {
+            __hip_atomic_store(pre + g, pre_pack(vout, k_out, vb_out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gstate[0] = vin;
+            gstate[1] = K;
+            gstate[2] = vb;
+            if (g + 1 == groups) {
+                result->status = PQ_OK;
+                result->n_entries = k_out;
+                result->n_values = vb_out;
+                result->reserved = 0;
+                offsets[k_out] = vb_out;
+            }
+        }
+    }
+    __syncthreads();
+    if (steps == 0u) return;
+
+    // ---- the state that enters this tile, then its entries (as entries_write_kernel) ----
+    uint32_t vin = uni(gstate[0]), K = uni(gstate[1]), vb = uni(gstate[2]);
+    for (uint32_t w = 0; w < wave; ++w) {
+        K += uni(wsum[w][1 + vin]);
+        vb += uni(wsum[w][3 + vin]);
+        vin = (uni(wsum[w][0]) >> vin) & 1u;
+    }
+    const uint64_t xb = asm_chain_in(bc, vin);
+    uint64_t mx, my_v;
+    uint32_t vo;
+    asm_step(my_c, my_d, (uint32_t)(xb >> lane) & 1u, mx, my_v, vo);
+    const uint64_t my_h = ~(my_c & mx) & my_valid;
+    my_v &= my_valid;
+    const uint32_t hcnt = (uint32_t)__builtin_popcountll(my_h), vcnt = (uint32_t)__builtin_popcountll(my_v);
+    const uint32_t tile_entries = wave_sum_u32(hcnt);
+    (void)vcnt;
+    const uint32_t need = (uint32_t)__builtin_amdgcn_ballot_w64((my_h & ~my_v) != 0ull);
+
+    uint32_t *vb32 = vbytes[wave];
+    uint8_t *vb8 = reinterpret_cast<uint8_t *>(vb32);
+#pragma unroll
+    for (int k = 0; k < kAsmVbWords / kWave; ++k) vb32[lane + kWave * k] = 0;
+    wave_fence();
+    const uint32_t shift = K & 31u;
+    // A step's two masks come to the scalar side (four v_readlane); whether a lane's position opens
+    // an entry, and whether that entry has a value, is then the mask itself as the execution mask
+    // or select mask, and the entries and values in front of the step are running scalar counts.
+    const uint32_t n32 = (uint32_t)n;  // n < 2^30 on this path
+    uint32_t Ks = K, vbs = vb;
+    auto emit = [&](uint32_t s, int32_t dl) {
+        const uint64_t H = readlane_u64(my_h, s), v = readlane_u64(my_v, s);
+        const bool head = __builtin_amdgcn_inverse_ballot_w64(H);
+        const bool vbit = __builtin_amdgcn_inverse_ballot_w64(v);
+        const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(H >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H, 0u));
+        const uint32_t vr = __builtin_amdgcn_mbcnt_hi((uint32_t)(v >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)v, 0u));
+        const uint32_t e = Ks + r;
+        // entries never outnumber positions: the bound only keeps a damaged summary from
+        // turning into a store outside the caller's arrays
+        if (head && e < n32) {
+            offsets[e] = vbs + vr;
+            entry_def[e] = vbit ? max_def : dl;
+            vb8[shift + (e - K)] = vbit ? (uint8_t)1 : (uint8_t)0;
+        }
+        Ks += (uint32_t)__builtin_popcountll(H);
+        vbs += (uint32_t)__builtin_popcountll(v);
+    };
+    if (__builtin_amdgcn_ballot_w64((dbits >> 8) != 0u) == 0ull) {
+        // a whole tile whose levels were kept
+#pragma unroll
+        for (uint32_t s = 0; s < (uint32_t)kAsmSteps; ++s) emit(s, (int32_t)((dkeep[s >> 2] >> (8u * (s & 3u))) & 0xffu));
+    } else {
+        for (uint32_t s0 = 0; s0 < steps; s0 += 8) {
+            int32_t dls[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                dls[j] = max_def;
+                const uint64_t pos = base + (uint64_t)(s0 + j) * kWave + lane;
+                if (((need >> (s0 + j)) & 1u) != 0u && pos < n) dls[j] = def[pos];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                if (s0 + j >= steps) break;
+                emit(s0 + j, dls[j]);
+            }
+        }
+    }
+    wave_fence();
+    const uint32_t total_bits = shift + min(tile_entries, (uint32_t)kAsmTile);
+    const uint32_t w0 = K >> 5;
+    const uint64_t words_cap = (n + 31) / 32;
+    const uint32_t nwords = w0 >= words_cap ? 0u : (uint32_t)min((uint64_t)((total_bits + 31u) >> 5), words_cap - w0);
+    for (uint32_t wi = (uint32_t)lane; wi < nwords; wi += kWave) {
+        uint32_t d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = vb32[8 * wi + k];
+        uint32_t word = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) word |= (((d[k] * 0x01020408u) >> 24) & 0xfu) << (4 * k);
+        const bool whole = (wi != 0u || shift == 0u) && 32u * wi + 32u <= total_bits;
+        if (whole)
+            validity[w0 + wi] = word;
+        else if (word != 0u)
+            atomicOr(validity + w0 + wi, word);
+    }
+}
+
 // 32 levels -> W dwords per thread.
 template <int W>
 __global__ __launch_bounds__(256) void levels_pack_kernel(const int32_t *__restrict__ levels, uint64_t n,
@@ -552,6 +867,18 @@ hipError_t launch_column_entries(hipStream_t s, const int32_t *d_def, const int3
     uint32_t *group_sum = tile_sum + tiles * 8;
     hipError_t e = hipMemsetAsync(d_validity, 0, (size_t)((n + 31) / 32 * 4), s);
     if (e != hipSuccess) return e;
+    if (groups != 0 && n < kOnePassMaxN) {
+        // one launch: the group records (two 64-bit words per group) start at zero.  Groups of
+        // kOnePassWG / 64 tiles.  (Groups of 16 tiles instead of 4, to have fewer records to look
+        // back over, were no faster: the time is in the vector instructions of the write phase.)
+        const uint64_t big = (tiles + kOnePassWG / kWave - 1) / (kOnePassWG / kWave);
+        uint64_t *agg = reinterpret_cast<uint64_t *>(d_work);
+        e = hipMemsetAsync(agg, 0, (size_t)(big * 16), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(entries_onepass_kernel<kOnePassWG>, dim3((unsigned)big), dim3(kOnePassWG), 0, s, d_def, d_rep,
+                           n, max_def, max_rep, repeated, agg, agg + big, big, d_offsets, d_validity, d_entry_def, d_result);
+        return hipGetLastError();
+    }
     if (groups != 0)
         hipLaunchKernelGGL(entries_summary_kernel, dim3((unsigned)groups), dim3(kAsmWG), 0, s, d_def, d_rep, n, max_def,
                            max_rep, repeated, masks, tile_sum, group_sum);
@@ -600,7 +927,7 @@ hipError_t launch_column_entries_static(int device, hipStream_t s, const int32_t
     void *ptr = g_scratch[device];
     if (!ptr) return g_scratch_err[device] != hipSuccess ? g_scratch_err[device] : hipErrorNotInitialized;
     if (entries_workspace_bytes(n) > kStaticScratchBytes) return hipErrorInvalidValue;
-    // every word of the workspace a launch reads it has written before: nothing to clear
+    // the launcher clears the words of the workspace that have to start at zero
     return launch_column_entries(s, d_def, d_rep, n, max_def, max_rep, repeated, d_offsets, d_validity, d_entry_def,
                                  d_result, ptr);
 }

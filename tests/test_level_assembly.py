@@ -164,6 +164,27 @@ def test_column_entries_vs_oracle(ctx):
 
 
 @pytest.mark.gpu
+def test_column_entries_levels_beyond_a_byte(ctx):
+    """Definition levels that do not fit a byte (a maximum above 255, stray large or negative
+    levels in a column of small ones): the entries without a value return them unchanged."""
+    rng = np.random.default_rng(19)
+    n = 5 * 8192 + 3000
+    for repeated in (False, True):
+        for max_def, lo, hi in ((300, 0, 301), (65535, 0, 65536), (3, -4, 4), (3, 0, 4), (200, 0, 260)):
+            deff = rng.integers(lo, hi, size=n).astype(np.int32)
+            deff[rng.random(n) < 0.6] = max_def
+            if max_def == 3 and lo == 0:
+                deff[[100, 9000, 20000]] = [256, 1 << 20, -(1 << 31)]   # one stray level in three of the tiles
+            rep = (rng.random(n) < 0.7).astype(np.int32)
+            got = ctx.column_entries(deff, rep if repeated else None, max_def, 1, repeated)
+            want = O.column_entries(deff, rep, max_def, 1, repeated)
+            assert got["n_entries"] == want["n_entries"] and got["n_values"] == want["n_values"], (max_def, lo, repeated)
+            assert np.array_equal(got["offsets"], want["offsets"])
+            assert np.array_equal(got["entry_def"], want["entry_def"]), (max_def, lo, repeated)
+            assert np.array_equal(got["validity"], want["validity"])
+
+
+@pytest.mark.gpu
 def test_column_entries_long_chains(ctx):
     """Chains that cross many wave steps and tiles: one list of everything, all nulls, a value
     entry whose continuation positions are undefined (they still take values), alternating."""
