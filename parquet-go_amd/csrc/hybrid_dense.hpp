@@ -1,0 +1,389 @@
+// hybrid_dense.hpp — the tiles in the middle of a run-dense hybrid stream.
+//
+// Included by hybrid_wave.hpp, whose window, state and sink it shares.  A stream of short runs
+// (level streams, run-heavy dictionary keys, BOOLEAN RLE) is bound by the number of instructions a
+// tile costs, so the tiles that need none of the reference's checks have a loop of their own:
+//
+//   * a run is ONE kind of piece, {bit address of (virtual) tile position 0, bits per position}: a
+//     bit-packed run steps by the bit width, an RLE run steps by 0 and points at its value where it
+//     lies in the window (the value of a run carried over from an earlier tile is parked in a word
+//     behind the window) — the expansion has no case distinction per value;
+//   * run headers are parsed 64 byte positions at a time (one- and two-byte headers; the chain of
+//     real headers is followed on the scalar unit); whole runs that fit the tile are appended by
+//     their own lanes, the first run that does not fit becomes the pending run;
+//   * ONE place cuts runs: the pending run is cut at the end of the tile (in the middle of a group
+//     if need be: HwState::pskip) and at the end of the window, so a tile is full whenever the
+//     window can feed it, and every store of such a tile is a whole 16-byte piece;
+//   * anything unusual — a header of three bytes and more, an empty run, an RLE value too large,
+//     the last group of a stream, the end of the stream — ends the loop with the state untouched
+//     at that point, and the checked tile of hybrid_wave reproduces what the reference does
+//     (encoding/hybrid-decoder.go:70-170).
+#pragma once
+
+namespace pq {
+
+enum DnReason : uint32_t {
+    DN_DONE = 0,     // n values are out
+    DN_WINDOW = 1,   // the window is used up
+    DN_GENERIC = 2,  // the checked tile has to look at what comes next
+    DN_BULK = 3,     // a fresh bit-packed run of 32 groups and more is pending: the bulk path takes it
+    DN_NONE = 4,
+};
+
+constexpr uint32_t kDnOdd = 0xffffffffu;
+// bit address of the first of the two words that hold RLE values of carried-over runs
+constexpr uint32_t kDnConstBit = (uint32_t)(kHwChunk + 4 * kHwSlack) * 8u;
+// highest bit address a position outside the tile is clamped to
+constexpr uint32_t kDnMaxBit = kDnConstBit + 32u;
+
+// lane's bit of `mask` set ? a : 0, in one instruction
+__device__ __forceinline__ uint32_t dn_select(uint64_t mask, uint32_t a)
+{
+    uint32_t r;
+    asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(mask));
+    return r;
+}
+
+struct DnNext {
+    uint32_t kind;   // 0: no run pending; 1: RLE; 2: bit-packed
+    uint32_t count;  // repeats | groups
+    uint32_t value;  // RLE value
+    uint32_t o;      // kind == 0: window offset of the next header; else: just behind the pending run's header (and value)
+};
+
+// Parse candidate headers at window offsets o .. o + 63, follow the chain of real ones from lane 0,
+// append the leading runs that lie wholly in the window and fit `room` values to the tile (each by
+// its own lane), describe what follows in nx.  Returns the number of runs appended, kDnOdd when the
+// header at o itself is not a simple one.
+__device__ __forceinline__ uint32_t dn_span(HybridWaveLds &L, uint32_t o, uint32_t wl, const HwConst &hc, uint32_t room,
+                                            uint32_t np, uint32_t fill, uint32_t phase, int lane, uint32_t &values,
+                                            DnNext &nx)
+{
+    const uint32_t p = o + (uint32_t)lane;
+    const uint32_t i = p >> 2, sh = (p & 3u) * 8u;
+    const uint32_t d0 = L.window[i], d1 = L.window[i + 1], d2 = L.window[i + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh);  // bytes p .. p+3
+    const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, sh);  // bytes p+4 .. p+7
+    const bool two = (lo & 0x80u) != 0u;
+    const uint32_t hdr = two ? 2u : 1u;
+    const uint32_t h = two ? (lo & 0x7fu) | ((lo >> 1) & 0x3f80u) : lo & 0xffu;
+    const uint32_t cnt = h >> 1;
+    const bool isbp = (h & 1u) != 0u;
+    const uint32_t val = __builtin_amdgcn_alignbit(hi, lo, 8u * hdr) & hc.vbmask;
+    const uint32_t body = isbp ? __umul24(cnt, hc.w) : hc.vb;
+    const uint32_t hend = p + hdr + (isbp ? 0u : hc.vb);  // end of the header and, for RLE, its value
+    const uint32_t nvals = isbp ? cnt * 8u : cnt;
+    const bool ok = (lo & 0x8080u) != 0x8080u && cnt != 0u && hend <= wl && (isbp || (val & ~hc.wmask) == 0u);
+    const bool whole = p + hdr + body <= wl;
+    const uint32_t nextlane = (uint32_t)lane + hdr + body;
+    const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
+
+    // five scalar instructions between the v_readlane that writes `cur` and the one that uses it as
+    // its lane select cover the wait states that dependency needs
+    uint32_t cur;
+    uint64_t chain;
+    asm volatile("s_mov_b64 %[chain], 0\n\t"
+                 "s_mov_b32 %[cur], 0\n"
+                 "1:\n\t"
+                 "s_bitcmp1_b64 %[ok], %[cur]\n\t"
+                 "s_cbranch_scc0 2f\n\t"
+                 "s_bitset1_b64 %[chain], %[cur]\n\t"
+                 "v_readlane_b32 %[cur], %[next], %[cur]\n\t"
+                 "s_cmp_lt_u32 %[cur], 64\n\t"
+                 "s_cbranch_scc1 1b\n"
+                 "2:"
+                 : [chain] "=&s"(chain), [cur] "=&s"(cur)
+                 : [ok] "s"(okmask), [next] "v"(nextlane)
+                 : "scc");
+    values = 0;
+    nx.kind = 0;
+    nx.count = 0;
+    nx.value = 0;
+    nx.o = o;
+    if (chain == 0ull) return kDnOdd;
+
+    const uint32_t incl = wave_scan_u32(dn_select(chain, nvals));
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(chain >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)chain, 0u));
+    const bool fit = dn_select(chain, 1u) != 0u && whole && incl <= room && np + rank < (uint32_t)kWave;
+    const uint64_t tmask = __builtin_amdgcn_ballot_w64(fit);
+    if (tmask != 0ull) {
+        const uint32_t last = 63u - (uint32_t)__builtin_clzll(tmask);
+        values = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)last);
+    }
+    const uint64_t untaken = chain & ~tmask;
+    if (untaken != 0ull) {
+        const uint32_t u = (uint32_t)__builtin_ctzll(untaken);
+        const uint32_t hu = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)u);
+        const uint32_t eu = (uint32_t)__builtin_amdgcn_readlane((int)hend, (int)u);
+        nx.kind = (hu & 1u) != 0u ? 2u : 1u;
+        nx.count = hu >> 1;
+        nx.value = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)u);
+        nx.o = eu;
+    } else {
+        nx.o = o + cur;
+    }
+    if (fit) {
+        const uint32_t start = fill + incl - nvals;
+        const uint32_t at = (p + hdr) * 8u;
+        L.pieces[np + rank] = make_uint2(isbp ? at - __umul24(start, hc.w) : at, isbp ? hc.w : 0u);
+        reinterpret_cast<uint8_t *>(L.marks)[phase + start] = 1;
+    }
+    return (uint32_t)__builtin_popcountll(tmask);
+}
+
+// 32 bits of the window from bit address `bit` on
+__device__ __forceinline__ uint32_t dn_read(const uint32_t *lds, uint32_t bit)
+{
+    const uint32_t i = bit >> 5;
+    return __builtin_amdgcn_alignbit(lds[i + 1], lds[i], bit & 31u);
+}
+
+// Expand the tile: positions [0, clip) go to dst[v ... v + clip).  posv[q][k] is the tile position of
+// this lane's value k of quad q (256 q + 4 lane + k - phase: quads are 4-element aligned in memory).
+// RAGGED = false: phase == 0 and clip == 256 Q, every quad is whole.  SOLO: the tile is the one
+// piece {y0, s0} (a bit-packed one).
+template <int MODE, typename OutT, int Q, bool RAGGED, bool SOLO>
+__device__ __forceinline__ void dn_expand(HybridWaveLds &L, const HwSink<OutT> &sink, uint32_t wmask,
+                                          const uint32_t (&posv)[Q][4], uint32_t y0, uint32_t s0, uint32_t clip,
+                                          uint32_t phase, uint32_t v, int lane, uint32_t &local_count, bool &bad_index)
+{
+    uint32_t key[Q][4];
+    if (SOLO) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t bit = __umul24(posv[q][k], s0) + y0;
+                if (RAGGED) bit = min(bit, kDnMaxBit);
+                key[q][k] = dn_read(L.window, bit) & wmask;
+            }
+    } else {
+        uint32_t x[Q], packed = 0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            uint32_t m = L.marks[kWave * q + lane];
+            m += m << 8;
+            m += m << 16;  // byte k = pieces started at or before position k of this quad
+            x[q] = m;
+            packed |= (m >> 24) << (8 * q);
+        }
+        const uint32_t incl = wave_scan_u32(packed);
+        const uint32_t tot = wave_last_u32(incl);
+        uint32_t before = 0xffffffffu;  // pieces started in the quads of lower q, less one
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const uint32_t excl = before + ((incl >> (8 * q)) & 0xffu) - (x[q] >> 24);
+            before += (tot >> (8 * q)) & 0xffu;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t id = excl + ((x[q] >> (8 * k)) & 0xffu);
+                if (RAGGED) id &= (uint32_t)(kWave - 1);
+                const uint2 rec = L.pieces[id];
+                uint32_t bit = __umul24(posv[q][k], rec.y) + rec.x;
+                if (RAGGED) bit = min(bit, kDnMaxBit);
+                key[q][k] = dn_read(L.window, bit) & wmask;
+            }
+        }
+    }
+    OutT *const qp0 = sink.dst + ((int64_t)v - (int64_t)phase + 4 * (int64_t)lane);  // quad q: + 256 q
+    const uint32_t dmax = sink.dict_len - 1u;  // no_dict: wraps, every comparison below still holds
+    if (!RAGGED) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            OutT out[4];
+            if (MODE == HY_DICT) {
+                const uint32_t top = max(max(key[q][0], key[q][1]), max(key[q][2], key[q][3]));
+                bad_index |= top > dmax || sink.no_dict;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) out[k] = sink.dict[sink.no_dict ? 0u : min(key[q][k], dmax)];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) out[k] = (OutT)key[q][k];
+                if (MODE == HY_LEVELS) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) local_count += key[q][k] == sink.max_level ? 1u : 0u;
+                }
+            }
+            hw_store4<OutT>(qp0 + 256 * q, out, 0xfu, true);
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        OutT out[4];
+        uint32_t valid = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = posv[q][k] < clip;  // also false "below zero"
+            valid |= ok ? 1u << k : 0u;
+            if (MODE == HY_DICT) {
+                const bool inside = key[q][k] <= dmax && !sink.no_dict;
+                bad_index |= ok && !inside;
+                out[k] = sink.dict[inside ? key[q][k] : 0u];
+            } else {
+                out[k] = (OutT)key[q][k];
+                if (MODE == HY_LEVELS) local_count += (ok && key[q][k] == sink.max_level) ? 1u : 0u;
+            }
+        }
+        if (valid != 0u) hw_store4<OutT>(qp0 + 256 * q, out, valid, true);
+    }
+}
+
+// A tile that is one RLE piece: a constant.
+template <int MODE, typename OutT, int Q>
+__device__ __forceinline__ void dn_expand_const(const HwSink<OutT> &sink, uint32_t key, const uint32_t (&posv)[Q][4],
+                                                uint32_t clip, uint32_t phase, uint32_t v, int lane, uint32_t &scount,
+                                                bool &bad_index)
+{
+    OutT o;
+    if (MODE == HY_DICT) {
+        const bool inside = key < sink.dict_len && !sink.no_dict;
+        if (!inside) bad_index = true;
+        o = sink.dict[inside ? key : 0u];
+    } else {
+        o = (OutT)key;
+        if (MODE == HY_LEVELS && key == sink.max_level) scount += clip;
+    }
+    OutT out[4] = {o, o, o, o};
+    OutT *const qp0 = sink.dst + ((int64_t)v - (int64_t)phase + 4 * (int64_t)lane);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        uint32_t valid = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) valid |= posv[q][k] < clip ? 1u << k : 0u;
+        if (valid != 0u) hw_store4<OutT>(qp0 + 256 * q, out, valid, true);
+    }
+}
+
+// Tiles of 256 Q values for as long as nothing needs the reference's checks.  On return the state
+// describes exactly what is out: st.v values, the next byte (or the pending run) at st.o.
+// allow_bulk = false: a fresh long bit-packed run is cut here like any other (the bulk path has just
+// declined it).
+template <int MODE, typename OutT, int Q>
+__device__ __forceinline__ uint32_t hw_dense_tiles(HybridWaveLds &L, HwState &st, const HwSink<OutT> &sink,
+                                                   const HwConst &hc, uint32_t n, uint32_t mis, uint32_t wl,
+                                                   uint32_t o_end, bool tail, uint32_t rw, bool allow_bulk, int lane,
+                                                   uint32_t &local_count, uint32_t &scount, bool &bad_index)
+{
+    constexpr uint32_t TILE = 256u * Q;
+    const uint32_t w = hc.w;
+    uint32_t cur_phase = 4;  // none yet
+    uint32_t posv[Q][4];
+    uint32_t cslot = 0;
+    for (;;) {
+        if (st.v >= n) return DN_DONE;
+        const uint32_t phase = (st.v + mis) & 3u;
+        if (phase != cur_phase) {
+            cur_phase = phase;
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) posv[q][k] = 4u * (uint32_t)lane + (uint32_t)(256 * q + k) - phase;
+        }
+        const uint32_t cap = TILE - phase;
+        const uint32_t want = min(cap, n - st.v);
+        uint32_t fill = 0, np = 0, reason = DN_NONE;
+        while (fill < want && np < (uint32_t)kWave) {
+            if (st.pend == 1u) {
+                const uint32_t take = min(st.pcount, want - fill);
+                cslot ^= 1u;
+                if (lane == 0) {
+                    L.window[kHwChunk / 4 + kHwSlack + cslot] = st.pvalue;
+                    L.pieces[np] = make_uint2(kDnConstBit + 32u * cslot, 0u);
+                    reinterpret_cast<uint8_t *>(L.marks)[phase + fill] = 1;
+                }
+                ++np;
+                fill += take;
+                st.pcount -= take;
+                if (st.pcount == 0u) st.pend = 0;
+            } else if (st.pend == 2u) {
+                const bool fresh_long = allow_bulk && st.pskip == 0u && st.pcount >= 32u;
+                if (fresh_long && (fill == 0u || 2u * fill >= cap)) {
+                    reason = DN_BULK;
+                    break;
+                }
+                // groups that lie wholly in the window
+                const uint32_t bytes = st.o < wl ? wl - st.o : 0u;
+                uint32_t gfit = (bytes * rw) >> 16;  // floor(bytes / w), or one more
+                if (gfit * w > bytes) --gfit;
+                const uint32_t gav = min(st.pcount, gfit);
+                if (8u * gav <= st.pskip) {
+                    reason = tail ? DN_GENERIC : DN_WINDOW;
+                    break;
+                }
+                const uint32_t avail = 8u * gav - st.pskip;
+                uint32_t take = min(avail, want - fill);
+                uint32_t t = st.pskip + take;
+                // what is left of a long run goes back to the bulk path: cut it between two groups
+                // (the tile closes a few values short)
+                bool shortened = false;
+                if (allow_bulk && (t & 7u) != 0u && take > (t & 7u) && st.pcount - (t >> 3) >= 32u) {
+                    take -= t & 7u;
+                    t = st.pskip + take;
+                    shortened = true;
+                }
+                if (lane == 0) {
+                    L.pieces[np] = make_uint2(st.o * 8u + st.pskip * w - fill * w, w);
+                    reinterpret_cast<uint8_t *>(L.marks)[phase + fill] = 1;
+                }
+                ++np;
+                fill += take;
+                const uint32_t adv = t >> 3;
+                st.o += adv * w;
+                st.pcount -= adv;
+                st.pskip = t & 7u;
+                if (st.pcount == 0u) st.pend = 0;
+                if (shortened) break;
+            } else {
+                if (st.o >= o_end) { reason = DN_WINDOW; break; }
+                if (st.o >= wl) { reason = DN_GENERIC; break; }
+                uint32_t values;
+                DnNext nx;
+                const uint32_t taken = dn_span(L, st.o, wl, hc, want - fill, np, fill, phase, lane, values, nx);
+                if (taken == kDnOdd) { reason = DN_GENERIC; break; }
+                np += taken;
+                fill += values;
+                st.o = nx.o;
+                if (nx.kind != 0u) {
+                    st.pend = nx.kind;
+                    st.pcount = nx.count;
+                    st.pvalue = nx.value;
+                    st.pskip = 0;
+                }
+            }
+        }
+        const uint32_t clip = fill;
+        if (clip != 0u) {
+            wave_sync();
+            const bool full = phase == 0u && clip == TILE;
+            if (np == 1u) {
+                const uint2 r0 = L.pieces[0];
+                const uint32_t y0 = uni(r0.x), s0 = uni(r0.y);
+                if (s0 == 0u) {
+                    const uint32_t key = uni(dn_read(L.window, y0)) & hc.wmask;
+                    dn_expand_const<MODE, OutT, Q>(sink, key, posv, clip, phase, st.v, lane, scount, bad_index);
+                } else if (full) {
+                    dn_expand<MODE, OutT, Q, false, true>(L, sink, hc.wmask, posv, y0, s0, clip, phase, st.v, lane,
+                                                          local_count, bad_index);
+                } else {
+                    dn_expand<MODE, OutT, Q, true, true>(L, sink, hc.wmask, posv, y0, s0, clip, phase, st.v, lane,
+                                                         local_count, bad_index);
+                }
+            } else if (full) {
+                dn_expand<MODE, OutT, Q, false, false>(L, sink, hc.wmask, posv, 0, 0, clip, phase, st.v, lane, local_count,
+                                                       bad_index);
+            } else {
+                dn_expand<MODE, OutT, Q, true, false>(L, sink, hc.wmask, posv, 0, 0, clip, phase, st.v, lane, local_count,
+                                                      bad_index);
+            }
+            wave_sync();  // the marks were read; the next tile sets its own
+#pragma unroll
+            for (int q = 0; q < Q; ++q) L.marks[kWave * q + lane] = 0;
+            wave_sync();
+            st.v += clip;
+        }
+        if (reason != DN_NONE) return reason;
+    }
+}
+
+}  // namespace pq

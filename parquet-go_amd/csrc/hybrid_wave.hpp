@@ -27,11 +27,13 @@ constexpr int kHwStride = kHwChunk - kHwGuard;  // distance between consecutive 
 constexpr int kHwQuads = 2;                     // 4-value quads per lane and tile
 constexpr int kHwTile = 256 * kHwQuads;         // values per tile
 constexpr int kHwSlack = 12;                    // zeroed words behind the window (a last group may hang over)
+constexpr int kHwConstWords = 4;                // behind them: RLE values of runs carried from tile to tile
+constexpr int kDnQuads = 2;                     // quads per lane and tile of the run-dense tiles
 constexpr uint32_t kHwMaxBit = (uint32_t)(kHwChunk + 4 * kHwSlack - 8) * 8u;  // highest bit address a funnel read may use
 
 struct HybridWaveLds {
-    uint32_t window[kHwChunk / 4 + kHwSlack];
-    uint32_t marks[kHwTile / 4];  // one byte per tile position: 1 = a piece starts here
+    uint32_t window[kHwChunk / 4 + kHwSlack + kHwConstWords];
+    uint32_t marks[kWave * 4];  // one byte per tile position: 1 = a piece starts here (tiles of up to 1024)
     uint2 pieces[kWave];    // RLE piece: x = ~0, y = the value; bit-packed: x = 0, y = bit address of
                             // (virtual) tile position 0, so that position j sits at y + j * w
 };
@@ -68,6 +70,7 @@ struct HwState {
     uint32_t v;       // values produced so far
     uint32_t pend;    // unfinished run: 0 none, 1 RLE, 2 bit-packed
     uint32_t pcount;  // RLE: repeats left; bit-packed: groups left
+    uint32_t pskip;   // bit-packed: values of the first of those groups that are out already (0..7)
     uint32_t pvalue;  // RLE value
     int32_t status;
 };
@@ -446,6 +449,12 @@ __device__ __forceinline__ void hw_expand(HybridWaveLds &L, const HwSink<OutT> &
     }
 }
 
+}  // namespace pq
+
+#include "hybrid_dense.hpp"
+
+namespace pq {
+
 // Decode n values of the stream [S, S + len) at bit width w into dst with ONE wave.
 // Modes as in hybrid_stream.  `dict` may point to LDS or global memory.  raw_groups != 0: the
 // stream has no run headers at all, it is that many bit-packed groups (PLAIN fixed-width values
@@ -478,9 +487,9 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
     WavePrefetch pf;
     int64_t c0 = chunk_base(S, 0);
     wave_fetch(pf, S, c0, len, lane);
-    if (lane < kHwSlack) L.window[kHwChunk / 4 + lane] = 0;
+    if (lane < kHwSlack + kHwConstWords) L.window[kHwChunk / 4 + lane] = 0;
 #pragma unroll
-    for (int q = 0; q < kHwQuads; ++q) L.marks[kWave * q + lane] = 0;
+    for (int q = 0; q < 4; ++q) L.marks[kWave * q + lane] = 0;
     wave_commit_clean(L.window, pf, c0, len, lane);
     wave_sync();
 
@@ -489,6 +498,7 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
     st.v = 0;
     st.pend = raw_groups != 0u ? 2u : 0u;
     st.pcount = raw_groups;
+    st.pskip = 0;
     st.pvalue = 0;
     st.status = PQ_OK;
 
@@ -509,6 +519,8 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
     sink.vec_ok = vec_ok;
 
     uint32_t local_count = 0;  // LEVELS: values equal to max_level seen by this lane
+    uint32_t scount = 0;       // LEVELS: the same, counted for whole tiles of one RLE run
+    uint32_t stuck_v = 0xffffffffu;  // st.v when the run-dense tiles last handed a run to the bulk path
     bool bad_index = false;    // DICT: a key outside the dictionary seen by this lane
 
     while (true) {
@@ -532,7 +544,7 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
                 if (b0 >= 0x80u || (b0 & 1u) == 0u || b0 < 65u) break;  // not a one-byte header of >= 32 groups
                 groups = b0 >> 1;
                 o += 1u;
-            } else if (st.pend != 2) {
+            } else if (st.pend != 2 || st.pskip != 0u) {
                 break;
             }
             const uint32_t phase = (st.v + mis) & 3u;
@@ -590,6 +602,16 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
             st.pend = st.pcount != 0u ? 2u : 0u;
         }
         if (st.v >= n) { done = true; break; }
+
+        // ---- run-dense tiles: everything that needs none of the checks below ----
+        if (vec_ok) {
+            const bool allow_bulk = st.v != stuck_v;
+            const uint32_t why = hw_dense_tiles<MODE, OutT, kDnQuads>(L, st, sink, hc, n, mis, wl, o_end, tail, rw,
+                                                                       allow_bulk, lane, local_count, scount, bad_index);
+            if (why == DN_DONE) { done = true; break; }
+            if (why == DN_WINDOW) break;
+            if (why == DN_BULK) { stuck_v = st.v; continue; }
+        }
 
         // ---- one tile of anything else ----
         {
@@ -655,7 +677,9 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
                 } else {
                     // readBitPackedRun (hybrid-decoder.go:138-149): a group is readable while at
                     // least one byte is left; pieces are whole groups that lie inside the window
-                    uint32_t g = min(st.pcount, min((cap - fill) >> 3, (want - fill + 7u) >> 3));
+                    // (the first group may have lost st.pskip values to a run-dense tile)
+                    const uint32_t sk = st.pskip;
+                    uint32_t g = min(st.pcount, min((cap - fill + sk) >> 3, (want - fill + sk + 7u) >> 3));
                     if (g == 0) break;  // fewer than 8 positions left in the tile
                     if (st.o + g * w > wl) {
                         if (st.o >= lim) { st.status = PQ_EOF; break; }
@@ -665,16 +689,17 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
                         if (g == 0) { want_window = true; break; }
                     }
                     // a tile left with fewer than 16 free positions is closed
-                    const bool closes = fill + 8u * g + 16u > want;
+                    const bool closes = fill + 8u * g - sk + 16u > want;
                     if (np == 0 && closes) {
                         solo = true;
                         sk0 = 0;
-                        pl0 = st.o * 8u;
+                        pl0 = st.o * 8u + sk * w;
                     } else {
-                        put_piece(L, np, 0u, st.o * 8u - fill * w, fill + phase, lane);
+                        put_piece(L, np, 0u, st.o * 8u + sk * w - fill * w, fill + phase, lane);
                     }
                     ++np;
-                    fill += 8u * g;
+                    st.pskip = 0;
+                    fill += 8u * g - sk;
                     st.o += g * w;
                     st.pcount -= g;
                     if (st.pcount == 0) st.pend = 0;
@@ -705,10 +730,11 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
         st.o -= (uint32_t)kHwStride;
     }
 
-    if (MODE == HY_LEVELS) res.count_max = wave_sum_u32(local_count);
+    if (MODE == HY_LEVELS) res.count_max = wave_sum_u32(local_count) + scount;
     res.status = st.status;
     res.n_decoded = st.v;
-    const int64_t pos = c0 + (int64_t)st.o;
+    // a group some of whose values are out has been read whole (readBitPackedRun)
+    const int64_t pos = c0 + (int64_t)st.o + (st.pend == 2u && st.pskip != 0u ? (int64_t)w : 0);
     res.consumed = (uint64_t)min(pos, len);
     if (MODE == HY_DICT && __builtin_amdgcn_ballot_w64(bad_index) != 0ull) {
         // DictDecoder.DecodeValues returns (0, "invalid index") (types/dict.go:104-111)
