@@ -33,7 +33,7 @@ constexpr uint32_t kHwMaxBit = (uint32_t)(kHwChunk + 4 * kHwSlack - 8) * 8u;  //
 
 struct HybridWaveLds {
     uint32_t window[kHwChunk / 4 + kHwSlack + kHwConstWords];
-    uint32_t marks[kWave * 4];  // one byte per tile position: 1 = a piece starts here (tiles of up to 1024)
+    uint32_t marks[kWave * kDnQuads];  // one byte per tile position: 1 = a piece starts here
     uint2 pieces[kWave];    // RLE piece: x = ~0, y = the value; bit-packed: x = 0, y = bit address of
                             // (virtual) tile position 0, so that position j sits at y + j * w
 };
@@ -489,7 +489,7 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
     wave_fetch(pf, S, c0, len, lane);
     if (lane < kHwSlack + kHwConstWords) L.window[kHwChunk / 4 + lane] = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) L.marks[kWave * q + lane] = 0;
+    for (int q = 0; q < kDnQuads; ++q) L.marks[kWave * q + lane] = 0;
     wave_commit_clean(L.window, pf, c0, len, lane);
     wave_sync();
 
