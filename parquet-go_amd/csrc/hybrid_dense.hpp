@@ -163,6 +163,7 @@ __device__ __forceinline__ void dn_expand(HybridWaveLds &L, const HwSink<OutT> &
         for (int q = 0; q < Q; ++q) {
             uint32_t m = L.marks[kWave * q + lane];
             m += m << 8;
+            asm volatile("" : "+v"(m));  // two shift-adds, not a multiplication by 0x01010101 (quarter rate)
             m += m << 16;  // byte k = pieces started at or before position k of this quad
             x[q] = m;
             packed |= (m >> 24) << (8 * q);

@@ -808,9 +808,9 @@ __global__ __launch_bounds__(kHwWG) void data_wave_kernel(const pq_page_desc *__
     uint32_t not_null = 0;
     if (size != 0) {
         const bool zeros_out = (d.flags & PQ_FLAG_NO_LEVEL_OUTPUT) == 0u;
+        // (the count of repetition levels equal to the maximum is never used: layout/page-v1.go:88-101)
         HybridResult rr = konst ? const_levels_wave(rep_dst, size, d.max_rep, lane, zeros_out)
-                                : run_section_wave<HY_LEVELS, uint32_t>(L, rep, wr, size, rep_dst, nullptr, 0,
-                                                                         d.max_rep, lane);
+                                : run_section_wave<HY_RAW, uint32_t>(L, rep, wr, size, rep_dst, nullptr, 0, 0, lane);
         if (rr.status != PQ_OK) {
             lvl_status = rr.status;
             lvl_stage = PQ_STAGE_REP;
