@@ -706,6 +706,32 @@ __global__ __launch_bounds__(WG) void entries_onepass_kernel(const int32_t *__re
     (void)vcnt;
     const uint32_t need = (uint32_t)__builtin_amdgcn_ballot_w64((my_h & ~my_v) != 0ull);
 
+    const uint32_t n32 = (uint32_t)n;  // n < 2^30 on this path
+    if (!repeated && (K & 63u) == 0u && steps == (uint32_t)kAsmSteps && base + kAsmTile <= n &&
+        (uint64_t)K + kAsmTile <= n && __builtin_amdgcn_ballot_w64((dbits >> 8) != 0u) == 0ull) {
+        // A whole tile of a column that is not REPEATED: every position opens an entry, so entry e is
+        // position e, a step's validity bits are its value mask as it stands (lane s holds those of
+        // step s and stores them itself) and nothing goes through LDS.
+        // (a whole tile lies inside the column, so its 64 validity words lie inside the caller's array)
+        if (lane < kAsmSteps) {
+            validity[(K >> 5) + 2u * (uint32_t)lane] = (uint32_t)my_v;
+            validity[(K >> 5) + 2u * (uint32_t)lane + 1u] = (uint32_t)(my_v >> 32);
+        }
+        uint32_t vbs = vb;
+        uint32_t *op = offsets + K + lane;
+        int32_t *ep = entry_def + K + lane;
+#pragma unroll
+        for (uint32_t s = 0; s < (uint32_t)kAsmSteps; ++s) {
+            const uint64_t v = readlane_u64(my_v, s);
+            const bool vbit = __builtin_amdgcn_inverse_ballot_w64(v);
+            const uint32_t vr = __builtin_amdgcn_mbcnt_hi((uint32_t)(v >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)v, 0u));
+            op[s * kWave] = vbs + vr;
+            ep[s * kWave] = vbit ? max_def : (int32_t)((dkeep[s >> 2] >> (8u * (s & 3u))) & 0xffu);
+            vbs += (uint32_t)__builtin_popcountll(v);
+        }
+        return;
+    }
+
     uint32_t *vb32 = vbytes[wave];
     uint8_t *vb8 = reinterpret_cast<uint8_t *>(vb32);
 #pragma unroll
@@ -715,7 +741,6 @@ __global__ __launch_bounds__(WG) void entries_onepass_kernel(const int32_t *__re
     // A step's two masks come to the scalar side (four v_readlane); whether a lane's position opens
     // an entry, and whether that entry has a value, is then the mask itself as the execution mask
     // or select mask, and the entries and values in front of the step are running scalar counts.
-    const uint32_t n32 = (uint32_t)n;  // n < 2^30 on this path
     uint32_t Ks = K, vbs = vb;
     auto emit = [&](uint32_t s, int32_t dl) {
         const uint64_t H = readlane_u64(my_h, s), v = readlane_u64(my_v, s);

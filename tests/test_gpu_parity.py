@@ -265,6 +265,36 @@ def test_hybrid_structured_runs_stress(ctx):
         _check_hybrid(c, c.w)
 
 
+def test_hybrid_pull_ends_inside_a_group(ctx):
+    """The pull stops at every position of a bit-packed group, behind RLE runs of every length modulo
+    8: run-dense tiles cut a run in the middle of a group, and the bytes reported as consumed are those
+    of the whole group (readBitPackedRun reads it whole, encoding/hybrid-decoder.go:138-149)."""
+    rng = _rng(33)
+    cases = []
+    for w in (1, 2, 3, 7, 8, 12, 17, 32):
+        vb = (w + 7) // 8
+        for lead in range(1, 10):
+            out = bytearray()
+            total = 0
+            # enough short runs to fill several tiles of 512 values and cross a 3 KiB window at w >= 12
+            for r in range(160):
+                cnt = lead + (r % 5)
+                out += bytes(synth.uleb128(cnt << 1)) + int(rng.integers(0, 1 << min(w, 31))).to_bytes(8, "little")[:vb]
+                total += cnt
+                g = 1 + (r % 4)
+                out += bytes(synth.uleb128((g << 1) | 1)) + rng.integers(0, 256, size=g * w, dtype=np.uint8).tobytes()
+                total += 8 * g
+            s = np.frombuffer(bytes(out), dtype=np.uint8).copy()
+            for cut in range(0, 9):
+                c = Case(K.KIND_HYBRID, s, total - cut, bit_width=w)
+                c.w, c.result_src_len = w, s.size
+                cases.append(c)
+    run_cases(ctx, cases, seed=8)
+    for c in cases:
+        _check_hybrid(c, c.w)
+        assert c.result["status"] == K.OK
+
+
 # ---------------------------------------------------------------------------
 # a5: dictionary pages
 
