@@ -28,12 +28,13 @@ constexpr int kHwQuads = 2;                     // 4-value quads per lane and ti
 constexpr int kHwTile = 256 * kHwQuads;         // values per tile
 constexpr int kHwSlack = 12;                    // zeroed words behind the window (a last group may hang over)
 constexpr int kHwConstWords = 4;                // behind them: RLE values of runs carried from tile to tile
-constexpr int kDnQuads = 2;                     // quads per lane and tile of the run-dense tiles
+constexpr int kDnQuads = 2;                     // quads per lane and tile of the run-dense tiles: dictionary keys
+constexpr int kDnQuadsPlain = 4;                // ... values that are stored as they are (levels, booleans)
 constexpr uint32_t kHwMaxBit = (uint32_t)(kHwChunk + 4 * kHwSlack - 8) * 8u;  // highest bit address a funnel read may use
 
 struct HybridWaveLds {
     uint32_t window[kHwChunk / 4 + kHwSlack + kHwConstWords];
-    uint32_t marks[kWave * kDnQuads];  // one byte per tile position: 1 = a piece starts here
+    uint32_t marks[kWave * kDnQuadsPlain];  // one byte per tile position: 1 = a piece starts here
     uint2 pieces[kWave];    // RLE piece: x = ~0, y = the value; bit-packed: x = 0, y = bit address of
                             // (virtual) tile position 0, so that position j sits at y + j * w
 };
@@ -490,7 +491,7 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
     wave_fetch(pf, S, c0, len, lane);
     if (lane < kHwSlack + kHwConstWords) L.window[kHwChunk / 4 + lane] = 0;
 #pragma unroll
-    for (int q = 0; q < kDnQuads; ++q) L.marks[kWave * q + lane] = 0;
+    for (int q = 0; q < kDnQuadsPlain; ++q) L.marks[kWave * q + lane] = 0;
     wave_commit_clean(L.window, pf, c0, len, lane);
     wave_sync();
 
@@ -607,8 +608,8 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
         // ---- run-dense tiles: everything that needs none of the checks below ----
         if (vec_ok) {
             const bool allow_bulk = st.v != stuck_v;
-            const uint32_t why = hw_dense_tiles<MODE, OutT, kDnQuads>(L, st, sink, hc, n, mis, wl, o_end, tail, rw,
-                                                                       allow_bulk, lane, local_count, scount, bad_index);
+            const uint32_t why = hw_dense_tiles<MODE, OutT, MODE == HY_DICT ? kDnQuads : kDnQuadsPlain>(
+                L, st, sink, hc, n, mis, wl, o_end, tail, rw, allow_bulk, lane, local_count, scount, bad_index);
             if (why == DN_DONE) { done = true; break; }
             if (why == DN_WINDOW) break;
             if (why == DN_BULK) { stuck_v = st.v; continue; }
