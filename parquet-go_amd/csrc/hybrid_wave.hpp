@@ -28,7 +28,7 @@ constexpr int kHwQuads = 2;                     // 4-value quads per lane and ti
 constexpr int kHwTile = 256 * kHwQuads;         // values per tile
 constexpr int kHwSlack = 12;                    // zeroed words behind the window (a last group may hang over)
 constexpr int kHwConstWords = 4;                // behind them: RLE values of runs carried from tile to tile
-constexpr int kDnQuads = 2;                     // quads per lane and tile of the run-dense tiles: dictionary keys
+constexpr int kDnQuads = 4;                     // quads per lane and tile of the run-dense tiles: dictionary keys
 constexpr int kDnQuadsPlain = 4;                // ... values that are stored as they are (levels, booleans)
 constexpr uint32_t kHwMaxBit = (uint32_t)(kHwChunk + 4 * kHwSlack - 8) * 8u;  // highest bit address a funnel read may use
 
