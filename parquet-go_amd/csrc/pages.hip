@@ -616,16 +616,16 @@ __device__ __forceinline__ HybridResult dict_values_wave(HybridWaveLds &L, const
     return r;
 }
 
-// PLAIN values are headerless groups of width 32 (an 8-byte value is two of them), BOOLEAN
-// PLAIN bytes headerless groups of width 1: both ride the bulk path of hybrid_wave.
+// PLAIN values are copied as they are; BOOLEAN PLAIN bytes are headerless groups of width 1 and ride
+// the bulk path of hybrid_wave.
 __device__ __forceinline__ HybridResult plain_values_wave(HybridWaveLds &L, const uint8_t *S, int64_t len, uint32_t n,
                                                           uint32_t es, uint32_t *dst, int lane)
 {
     uint32_t n_ok;
     const HybridResult r = plain_result(len, n, es, &n_ok);
-    const uint32_t words = n_ok * (es / 4u);
-    if (words != 0u)
-        (void)hybrid_wave<HY_RAW, uint32_t>(L, S, len, 32u, words, dst, nullptr, 0, 0, lane, (words + 7u) >> 3);
+    // little-endian values are their own bytes: a copy, 16 bytes per lane and step
+    (void)L;
+    wave_copy_bytes(reinterpret_cast<uint8_t *>(dst), S, (uint64_t)n_ok * es, lane);
     return r;
 }
 
