@@ -725,8 +725,10 @@ __global__ __launch_bounds__(WG) void entries_onepass_kernel(const int32_t *__re
             const uint64_t v = readlane_u64(my_v, s);
             const bool vbit = __builtin_amdgcn_inverse_ballot_w64(v);
             const uint32_t vr = __builtin_amdgcn_mbcnt_hi((uint32_t)(v >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)v, 0u));
-            op[s * kWave] = vbs + vr;
-            ep[s * kWave] = vbit ? max_def : (int32_t)((dkeep[s >> 2] >> (8u * (s & 3u))) & 0xffu);
+            // written once, never read here: past the caches, so that they keep the levels still to come
+            __builtin_nontemporal_store(vbs + vr, op + s * kWave);
+            __builtin_nontemporal_store(vbit ? max_def : (int32_t)((dkeep[s >> 2] >> (8u * (s & 3u))) & 0xffu),
+                                        ep + s * kWave);
             vbs += (uint32_t)__builtin_popcountll(v);
         }
         return;
