@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kWG) void bitunpack_kernel(const uint8_t *__restric
                 pk = make_uint4((uint32_t)(uint64_t)out[0], (uint32_t)((uint64_t)out[0] >> 32),
                                 (uint32_t)(uint64_t)out[1], (uint32_t)((uint64_t)out[1] >> 32));
             }
-            *reinterpret_cast<uint4 *>(dst + gi) = pk;
+            store_nt16(dst + gi, pk.x, pk.y, pk.z, pk.w);  // written once: past the caches, which keep the input
         } else {
 #pragma unroll
             for (int j = 0; j < VPT; ++j) dst[gi + j] = out[j];
