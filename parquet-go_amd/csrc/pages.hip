@@ -634,8 +634,31 @@ __device__ __forceinline__ HybridResult bool_values_wave(HybridWaveLds &L, const
 {
     uint32_t n_ok;
     const HybridResult r = bool_result(len, n, &n_ok);
-    if (n_ok != 0u)
+    if (n_ok == 0u) return r;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15u) != 0u) {
         (void)hybrid_wave<HY_RAW, uint32_t>(L, S, len, 1u, n_ok, dst, nullptr, 0, 0, lane, (n_ok + 7u) >> 3);
+        return r;
+    }
+    // One bit a value, least significant first (types/boolean.go:86-101): a lane takes the four bits of
+    // values 4 lane .. 4 lane + 3 of a block of 256 (half a byte of the block's 32) and stores 16 bytes;
+    // four blocks a step, so that four loads are in flight.
+    const uint32_t blocks = n_ok >> 8;
+    const uint32_t half = (uint32_t)lane >> 1, sh = ((uint32_t)lane & 1u) * 4u;
+    for (uint32_t b0 = 0; b0 < blocks; b0 += 4u) {
+        uint32_t byte[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u)
+            byte[u] = b0 + u < blocks ? (uint32_t)S[32u * (size_t)(b0 + u) + half] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            if (b0 + u < blocks) {
+                const uint32_t nib = byte[u] >> sh;
+                store_nt16(dst + 256u * (size_t)(b0 + u) + 4u * (uint32_t)lane, nib & 1u, (nib >> 1) & 1u, (nib >> 2) & 1u,
+                           (nib >> 3) & 1u);
+            }
+        }
+    }
+    for (uint32_t i = 256u * blocks + (uint32_t)lane; i < n_ok; i += kWave) dst[i] = ((uint32_t)S[i >> 3] >> (i & 7u)) & 1u;
     return r;
 }
 
