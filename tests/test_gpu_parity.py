@@ -344,7 +344,9 @@ def test_levels_vs_oracle(ctx):
     rng = _rng(11)
     cases = []
     for max_level, n, mean_run in ((1, 20000, 4), (3, 20000, 5), (3, 100000, 1), (7, 999, 2), (255, 5000, 3),
-                                   (65535, 3000, 2), (0, 500, 1), (2, 0, 1)):
+                                   (65535, 3000, 2), (0, 500, 1), (2, 0, 1),
+                                   # long runs: whole tiles of one RLE run are counted without looking at their values
+                                   (3, 50000, 3000), (1, 30000, 300), (2, 70000, 20000)):
         bw = int(max_level).bit_length()
         vals = np.minimum(_runny(rng, n, bw, mean_run), max_level)
         stream = synth.hybrid_encode(vals, bw)
