@@ -179,8 +179,8 @@ def measured_traffic(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pages", type=int, default=5000)
     ap.add_argument("--values-per-page", type=int, default=20000)
     ap.add_argument("--width", type=int, default=16)

@@ -79,7 +79,7 @@ def test_segmented_pages_vs_oracle(ctx, bits, seg_bytes):
 
 @pytest.mark.parametrize("bits", [32, 64])
 def test_one_million_value_pages(ctx, bits):
-    """SURVEY's large-page shape (1 M values a page) under the segment length the library picks."""
+    """The large-page shape (1 M values a page) under the segment length the library picks."""
     rng = np.random.default_rng(7 + bits)
     dt = np.int32 if bits == 32 else np.int64
     cases = []
