@@ -360,14 +360,16 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
     auto load_word = [&](const uint32_t *base, uint32_t i) -> int32_t {
         return i < m ? (int32_t)__hip_atomic_load(base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
     };
-    int32_t cur_s = load_word(area, (uint32_t)lane);
+    int32_t cur_s = load_word(area, (uint32_t)lane), cur_p = load_word(P, (uint32_t)lane);
     res.consumed = init_consumed;
     for (uint32_t base = 0; base < m; base += kWave) {
-        // offsets[i + 1] takes the place of suffix length i + 1: load the next batch first
+        // offsets[i + 1] takes the place of suffix length i + 1: load the next batch first (the prefix
+        // lengths with it: a load inside the batch that needs it left the wave waiting once per batch)
         const int32_t next_s = load_word(area, base + kWave + (uint32_t)lane);
+        const int32_t next_p = load_word(P, base + kWave + (uint32_t)lane);
         const uint32_t i = base + (uint32_t)lane;
         const bool live = i < m;
-        const int32_t s = cur_s, p = load_word(P, i);
+        const int32_t s = cur_s, p = cur_p;
         const bool neg_s = live && s < 0;  // make([]byte, size) panics (:210)
         const uint64_t sincl = scarry + wave_scan_u64(live && !neg_s ? (uint64_t)(uint32_t)s : 0ull);
         const bool rd_fail = live && !neg_s && sincl > avail;                // io.ReadFull (:212)
@@ -407,6 +409,7 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
         prev_carry = (uint32_t)__builtin_amdgcn_readlane((int)vlen, 63);
         done = min(base + (uint32_t)kWave, m);
         cur_s = next_s;
+        cur_p = next_p;
         res.consumed = init_consumed + scarry;
     }
     if (lane == 0) area[0] = 0;

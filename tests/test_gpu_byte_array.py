@@ -326,3 +326,60 @@ def test_lengths_at_the_limits_of_the_one_pass_path(ctx):
         _check(c)
     seen = {int(c.result["status"]) for c in cases}
     assert {K.EOF, K.UNEXPECTED_EOF, K.BYTE_ARRAY_NEGATIVE_LEN} <= seen
+
+
+def _front_coded(rng, n, max_len, chain, alphabet=4):
+    """n values of at most max_len bytes, each keeping some bytes of the one in front.  chain: the
+    first `chain` bytes never change (no value but the first starts its suffix there), so whoever
+    starts in the middle of the list has to look all the way back for them."""
+    vals, prev = [], bytes(rng.integers(97, 97 + alphabet, size=max(chain, 1), dtype=np.uint8))
+    vals.append(prev)
+    for _ in range(n - 1):
+        ln = int(rng.integers(chain, max_len + 1))
+        keep = int(rng.integers(chain, min(len(prev), ln) + 1))
+        prev = prev[:keep] + bytes(rng.integers(97, 97 + alphabet, size=ln - keep, dtype=np.uint8))
+        vals.append(prev)
+    return vals
+
+
+@pytest.mark.parametrize("max_len", [1, 9, 16, 17, 32, 33, 64, 65, 128, 129, 256, 257])
+def test_short_values_of_every_length_class(ctx, max_len):
+    """Pages of values no longer than max_len (1 .. 257 bytes), front-coded: short and long lists,
+    prefixes that reach back to the first value of the page, pulls that end in the middle, value
+    areas with room to spare, a suffix area that runs out, a length list that fails in the middle."""
+    rng = np.random.default_rng(500 + max_len)
+    cases = []
+    for n, chain in ((100, 0), (129, 1), (511, 0), (512, 0), (513, 1), (700, 0), (2047, 0), (2048, 1), (3000, 0),
+                     (3000, min(3, max_len)), (20000 if max_len <= 33 else 5000, min(2, max_len))):
+        vals = _front_coded(rng, n, max_len, chain)
+        room = total_len(vals)
+        fs = synth.delta_ba_encode(vals)
+        for pull in (n, n - 1, n // 2 + 7, n // 4, 3):
+            cases.append(_case(K.KIND_DELTA_BA, fs, pull, data_cap=room))
+        for extra in (1, 5, 16):
+            cases.append(_case(K.KIND_DELTA_BA, fs, n, data_cap=room + extra))
+        cases.append(_case(K.KIND_DELTA_BA, fs[: fs.size - room // 3].copy(), n, data_cap=room))   # the bytes run out
+    # sorted words, as a dictionary of strings would be written
+    words = sorted(bytes(rng.integers(97, 123, size=int(rng.integers(min(3, max_len), max_len + 1)), dtype=np.uint8))
+                   for _ in range(6000))
+    cases.append(_case(K.KIND_DELTA_BA, synth.delta_ba_encode(words), 6000, data_cap=total_len(words)))
+    # a prefix longer than the value in front, past the first cut
+    n = 2000
+    sl = rng.integers(0, max_len // 2 + 1, size=n)
+    pl = np.zeros(n, np.int64)
+    prev = 0
+    for i in range(n):
+        pl[i] = int(rng.integers(0, min(prev, max_len - sl[i]) + 1))
+        prev = pl[i] + sl[i]
+    body = rng.integers(0, 256, size=int(sl.sum()), dtype=np.uint8)
+    cases.append(_case(K.KIND_DELTA_BA, dba_stream(pl, sl, body), n, data_cap=int((pl + sl).sum())))
+    bad = pl.copy()
+    bad[1500] = pl[1499] + sl[1499] + 1
+    cases.append(_case(K.KIND_DELTA_BA, dba_stream(bad, sl, body), n, data_cap=int((bad + sl).sum())))
+    neg = sl.copy()
+    neg[1200] = -1
+    cases.append(_case(K.KIND_DELTA_BA, dba_stream(pl, neg, body), n, data_cap=int((pl + sl).sum())))
+    run_cases(ctx, cases, seed=max_len)
+    for c in cases:
+        _check(c)
+    assert sum(1 for c in cases if c.result["status"] == K.OK and c.result["n_decoded"] >= 512) >= 20
