@@ -594,10 +594,10 @@ __global__ __launch_bounds__(WG) void entries_onepass_kernel(const int32_t *__re
         for (uint32_t s0 = 0; s0 < (uint32_t)kAsmSteps; s0 += 16) {
             int32_t dl[16], rl[16];
 #pragma unroll
-            for (uint32_t j = 0; j < 16; ++j) dl[j] = dp[(s0 + j) * kWave];
+            for (uint32_t j = 0; j < 16; ++j) dl[j] = __builtin_nontemporal_load(dp + (s0 + j) * kWave);  // read once
             if (repeated) {
 #pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) rl[j] = rp[(s0 + j) * kWave];
+                for (uint32_t j = 0; j < 16; ++j) rl[j] = __builtin_nontemporal_load(rp + (s0 + j) * kWave);
             }
 #pragma unroll
             for (uint32_t j = 0; j < 16; ++j) {

@@ -72,10 +72,10 @@ __device__ __forceinline__ void wave_copy_bytes(uint8_t *dst, const uint8_t *src
         for (int u = 0; u < kInFlight; ++u) {
             const uint64_t i = i0 + (uint64_t)kWave * u;
             if (i < pieces) {
-                v[u] = *reinterpret_cast<const u32x4_a4 *>(s32 + 4 * i);
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(s32 + 4 * i));
                 // the word behind the piece holds at least one source byte when the source is
                 // not word aligned (n >= 16 (i + 1)); it is not touched otherwise
-                e[u] = sh ? s32[4 * i + 4] : 0u;
+                e[u] = sh ? __builtin_nontemporal_load(s32 + 4 * i + 4) : 0u;
             }
         }
 #pragma unroll
