@@ -42,6 +42,10 @@ struct WalkReader {
     int lane;
 };
 
+constexpr int64_t kWkNone = INT64_MIN / 2;
+constexpr int64_t kWkHeaderRoom = 512;  // the fast path takes a header from a window that holds this much behind its
+                                        // first byte: one that ran out of window would go the careful way, byte by byte
+
 __device__ __forceinline__ int64_t wk_pos(const WalkReader &r) { return r.next - (int64_t)r.have; }
 
 // Move the read position (the register buffer is dropped).
@@ -51,12 +55,18 @@ __device__ __forceinline__ void wk_seek(WalkReader &r, int64_t pos)
     r.have = 0;
 }
 
+__device__ __forceinline__ uint4 wk_load_piece(const WalkReader &r, int64_t c0)
+{
+    const int64_t o = c0 + 16 * (int64_t)r.lane;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (o + 16 > 0 && o < r.len) v = *reinterpret_cast<const uint4 *>(r.S + o);
+    return v;
+}
+
 __device__ __forceinline__ void wk_stage(WalkReader &r, int64_t pos)
 {
     r.c0 = chunk_base(r.S, pos);
-    const int64_t o = r.c0 + 16 * (int64_t)r.lane;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (o + 16 > 0 && o < r.len) v = *reinterpret_cast<const uint4 *>(r.S + o);
+    const uint4 v = wk_load_piece(r, r.c0);
     wave_sync();
     reinterpret_cast<uint4 *>(r.lds)[r.lane] = v;
     wave_sync();
@@ -387,27 +397,57 @@ __device__ __forceinline__ uint32_t fw_varint(uint32_t x, uint32_t *value)
     return vl;
 }
 
-// Field header byte `hdr` followed by an i32 (zig-zag varint): false when the bytes say otherwise.
-__device__ __forceinline__ bool fw_i32(FastWin &f, const WalkReader &r, uint32_t &o, uint32_t hdr, int32_t *out)
+// The i32 fields of a header (field header byte 0x15, zig-zag varint) all at once: every lane decodes
+// the field that WOULD start at its byte of the 64 window bytes from offset `o` on, and the scalar
+// side follows the chain from field to field - a mask test and two v_readlane each instead of
+// eight bytes out of the window register and a varint decode (~ 45 scalar instructions).
+struct I32Span {
+    uint32_t byte;   // the window byte at o + lane
+    uint32_t value;  // the i32 behind it, were it a field header
+    uint32_t behind; // the lane behind that field
+    uint64_t good;   // lanes whose byte is 0x15 with a varint of at most four bytes behind it
+    uint32_t p;      // the lane the scalar side stands at
+};
+
+__device__ __forceinline__ void span_load(I32Span &sp, const WalkReader &r, uint32_t o)
 {
-    const uint64_t g = fw_get(f, r, o);
+    const uint32_t q = o + (uint32_t)r.lane;  // the window array has 64 words of slack behind it
+    const uint32_t *w = r.lds + (q >> 2);
+    const uint32_t sh = (q & 3u) * 8u;
+    const uint32_t lo = __builtin_amdgcn_alignbit(w[1], w[0], sh), hi = __builtin_amdgcn_alignbit(w[2], w[1], sh);
     uint32_t u = 0;
-    const uint32_t vl = fw_varint((uint32_t)(g >> 8), &u);
-    if (((uint32_t)g & 255u) != hdr || vl == 0u) return false;
-    *out = (int32_t)((u >> 1) ^ (0u - (u & 1u)));
-    o += 1u + vl;
+    const uint32_t vl = fw_varint((lo >> 8) | (hi << 24), &u);
+    sp.byte = lo & 255u;
+    sp.value = (u >> 1) ^ (0u - (u & 1u));
+    sp.behind = (uint32_t)r.lane + 1u + vl;
+    sp.good = __builtin_amdgcn_ballot_w64(sp.byte == 0x15u && vl != 0u);
+    sp.p = 0;
+}
+
+// the byte the scalar side stands at (p < 64)
+__device__ __forceinline__ uint32_t span_byte(const I32Span &sp)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)sp.byte, (int)sp.p);
+}
+
+// An i32 field at p: false when the bytes say otherwise (or the field might leave the 64 bytes).
+__device__ __forceinline__ bool span_i32(I32Span &sp, int32_t *out)
+{
+    if (sp.p > 58u || ((sp.good >> sp.p) & 1ull) == 0ull) return false;
+    *out = (int32_t)__builtin_amdgcn_readlane((int)sp.value, (int)sp.p);
+    sp.p = (uint32_t)__builtin_amdgcn_readlane((int)sp.behind, (int)sp.p);
     return true;
 }
 
 // `count` i32 fields with ids 1, 2, 3 ... into h.f[1 ..]
-__device__ __forceinline__ bool fw_i32_run(FastWin &f, const WalkReader &r, uint32_t &o, SubHeader &h, uint32_t count)
+__device__ __forceinline__ bool span_i32_run(I32Span &sp, SubHeader &h, uint32_t count)
 {
     bool ok = true;
 #pragma unroll
     for (uint32_t k = 1; k <= 6u; ++k) {
         if (k <= count) {
             int32_t v = 0;
-            ok = ok && fw_i32(f, r, o, 0x15u, &v);
+            ok = ok && span_i32(sp, &v);
             h.f[k] = v;
         }
     }
@@ -418,28 +458,48 @@ __device__ __forceinline__ bool fw_i32_run(FastWin &f, const WalkReader &r, uint
 
 // An optional Statistics struct (field header `hdr`) and the stop byte of the struct around it.
 // Binaries, i64 counts and booleans with one-byte field headers only; `lim` = window bytes inside the stream.
+//
+// Stepping over the fields one after the other on the scalar unit cost ~ 85 instructions a field
+// (eight bytes out of the window register, a varint, the type rules).  Instead every lane looks
+// at the field that WOULD start at its byte of the window - header byte, varint, type rules, and
+// with them the lane the next field starts at - and the scalar side only follows that chain:
+// two mask tests and one v_readlane a field.  A binary longer than the 64 bytes the lanes cover
+// ends the span; the next one starts where it ends.
 __device__ __forceinline__ bool fw_statistics_and_stop(FastWin &f, const WalkReader &r, uint32_t &o, uint32_t hdr,
                                                        uint32_t lim)
 {
     uint64_t g = fw_get(f, r, o);
     if (((uint32_t)g & 255u) == hdr) {
         o += 1u;
-        for (int k = 0; k < 10; ++k) {  // Statistics has eight fields: four binaries, two counts, two booleans
+        uint32_t fields = 0;  // Statistics has eight: four binaries, two counts, two booleans
+        bool at_stop = false;
+        while (!at_stop) {
             if (o + 12u > lim) return false;
-            g = fw_get(f, r, o);
-            const uint32_t b = (uint32_t)g & 255u;
-            if (b == 0u) break;
+            const uint32_t q = o + (uint32_t)r.lane;  // the window array has 64 words of slack behind it
+            const uint32_t *w = r.lds + (q >> 2);
+            const uint32_t sh = (q & 3u) * 8u;
+            const uint32_t lo = __builtin_amdgcn_alignbit(w[1], w[0], sh), hi = __builtin_amdgcn_alignbit(w[2], w[1], sh);
+            const uint32_t b = lo & 255u, t = b & 15u;
             uint32_t u = 0;
-            const uint32_t vl = fw_varint((uint32_t)(g >> 8), &u);
-            const uint32_t t = b & 15u;
+            const uint32_t vl = fw_varint((lo >> 8) | (hi << 24), &u);
             const bool flag = t == CT_TRUE || t == CT_FALSE;  // a boolean field is its header byte
-            if ((b >> 4) == 0u || (!flag && (vl == 0u || (t != CT_BINARY && t != CT_I64)))) return false;
-            o += flag ? 1u : 1u + vl + (t == CT_BINARY ? u : 0u);
+            const bool good = (b >> 4) != 0u && (flag || (vl != 0u && (t == CT_BINARY || t == CT_I64)));
+            const uint32_t behind = (uint32_t)r.lane + (flag ? 1u : 1u + vl + (t == CT_BINARY ? u : 0u));
+            const uint64_t stops = __builtin_amdgcn_ballot_w64(b == 0u), goods = __builtin_amdgcn_ballot_w64(good);
+            uint32_t p = 0;
+            while (true) {
+                if (o + p + 12u > lim) return false;
+                if (((stops >> p) & 1ull) != 0ull) {
+                    at_stop = true;
+                    break;
+                }
+                if (((goods >> p) & 1ull) == 0ull || ++fields > 10u) return false;
+                p = (uint32_t)__builtin_amdgcn_readlane((int)behind, (int)p);
+                if (p >= (uint32_t)kWave) break;
+            }
+            o += p;
         }
-        if (o + 12u > lim) return false;
-        g = fw_get(f, r, o);
-        if (((uint32_t)g & 255u) != 0u) return false;  // more than the loop allows, or not the struct's end
-        o += 1u;
+        o += 1u;  // the stop byte of Statistics
         g = fw_get(f, r, o);
     }
     if (((uint32_t)g & 255u) != 0u) return false;
@@ -453,41 +513,49 @@ __device__ __forceinline__ bool wk_fast_header(WalkReader &r, PageHeader &h)
 {
     const int64_t pos = wk_pos(r);
     if (pos >= r.len) return false;
-    if (pos < r.c0 || pos + 64 > r.c0 + kWkWin) wk_stage(r, pos);
+    if (pos < r.c0 || pos + kWkHeaderRoom > r.c0 + kWkWin) wk_stage(r, pos);
     const int64_t left = r.len - r.c0;
     const uint32_t lim = left < (int64_t)kWkWin ? (uint32_t)left : (uint32_t)kWkWin;  // staged bytes inside the stream
     uint32_t o = (uint32_t)(pos - r.c0);
     if (o + 64u > lim) return false;  // a header this close to the end goes the careful way
     FastWin f;
     fw_load(f, r, o);
+    I32Span sp;
+    span_load(sp, r, o);  // o + 64 <= lim: the 64 bytes are the stream's
+    const uint32_t o0 = o;
     h.type = h.uncompressed = h.compressed = 0;
     wk_clear(h.data);
     wk_clear(h.dict);
     wk_clear(h.v2);
-    if (!fw_i32(f, r, o, 0x15u, &h.type) || !fw_i32(f, r, o, 0x15u, &h.uncompressed) ||
-        !fw_i32(f, r, o, 0x15u, &h.compressed))
-        return false;
-    const uint32_t b = (uint32_t)fw_get(f, r, o) & 255u;
-    o += 1u;
+    if (!span_i32(sp, &h.type) || !span_i32(sp, &h.uncompressed) || !span_i32(sp, &h.compressed)) return false;
+    if (sp.p > 58u) return false;
+    const uint32_t b = span_byte(sp);
+    sp.p += 1u;
     bool ok;
     if (b == 0x2cu) {  // field 5: DataPageHeader
-        ok = fw_i32_run(f, r, o, h.data, 4u) && fw_statistics_and_stop(f, r, o, 0x1cu, lim);
+        ok = span_i32_run(sp, h.data, 4u);
+        o = o0 + sp.p;
+        ok = ok && fw_statistics_and_stop(f, r, o, 0x1cu, lim);
     } else if (b == 0x4cu) {  // field 7: DictionaryPageHeader, is_sorted optional
-        ok = fw_i32_run(f, r, o, h.dict, 2u);
-        const uint32_t s = (uint32_t)fw_get(f, r, o) & 255u;
-        if (s == 0x11u || s == 0x12u) o += 1u;
-        ok = ok && ((uint32_t)fw_get(f, r, o) & 255u) == 0u;
-        o += 1u;
+        ok = span_i32_run(sp, h.dict, 2u) && sp.p <= 58u;
+        if (!ok) return false;
+        const uint32_t s = span_byte(sp);
+        if (s == 0x11u || s == 0x12u) sp.p += 1u;
+        ok = span_byte(sp) == 0u;
+        sp.p += 1u;
+        o = o0 + sp.p;
     } else if (b == 0x5cu) {  // field 8: DataPageHeaderV2, is_compressed optional
-        ok = fw_i32_run(f, r, o, h.v2, 6u);
-        const uint32_t s = (uint32_t)fw_get(f, r, o) & 255u;
+        ok = span_i32_run(sp, h.v2, 6u) && sp.p <= 58u;
+        if (!ok) return false;
+        const uint32_t s = span_byte(sp);
         uint32_t stats_hdr = 0x2cu;  // Statistics is field 8: two past field 6 ...
         if (s == 0x11u || s == 0x12u) {
             h.v2.is_compressed = s == 0x11u ? 1u : 0u;
-            o += 1u;
+            sp.p += 1u;
             stats_hdr = 0x1cu;  // ... one past field 7
         }
-        ok = ok && fw_statistics_and_stop(f, r, o, stats_hdr, lim);
+        o = o0 + sp.p;
+        ok = fw_statistics_and_stop(f, r, o, stats_hdr, lim);
     } else {
         return false;
     }
@@ -547,7 +615,7 @@ __global__ __launch_bounds__(kWkWaves *kWave) void walk_chunks_kernel(const pq_c
     r.frames = s_frames[wave];
     r.S = src + c.src_off;
     r.len = (int64_t)c.src_len;
-    r.c0 = INT64_MIN / 2;
+    r.c0 = kWkNone;
     r.next = 0;
     r.buf = 0;
     r.have = 0;
