@@ -117,6 +117,51 @@ def test_unknown_fields_of_every_shape(ctx):
     _compare(ctx, chunks + cut)
 
 
+def test_statistics_of_every_shape(ctx):
+    """The shapes the walk's fast path takes in one go, and the ones just outside: binaries whose length
+    needs one and two varint bytes and that end on, one short of and one past the 64 bytes a span of
+    lanes covers; counts of one to five varint bytes (five leave the fast path); up to ten fields, then
+    eleven; a long-form field id; headers longer than what a window keeps behind a header's first byte;
+    page bodies so short that several headers share a window; every page kind."""
+    from parquet_go_amd import synth
+    rng = np.random.default_rng(25)
+    H = synth.page_header
+    blob = lambda n: bytes(rng.integers(0, 256, size=n, dtype=np.uint8))
+    stats = []
+    for n in (0, 1, 2, 50, 58, 59, 60, 61, 62, 63, 64, 65, 66, 126, 127, 128, 129, 200, 300, 470, 520, 700, 1100):
+        stats.append([(1, "binary", blob(n)), (2, "binary", b"ab"), (3, "i64", 5), (4, "i64", 77), (5, "binary", blob(n // 2)),
+                      (6, "binary", b""), (7, "bool", True), (8, "bool", False)])
+        stats.append([(5, "binary", blob(n)), (6, "binary", blob(n))])
+    for count in (1, 127, 128, 1 << 14, 1 << 21, 1 << 27, 1 << 28, 1 << 40, -1, -(1 << 30)):
+        stats.append([(3, "i64", count), (4, "i64", -count)])
+    stats.append([(k, "bool", bool(k & 1)) for k in range(1, 11)])               # ten fields
+    stats.append([(k, "bool", bool(k & 1)) for k in range(1, 12)])               # eleven
+    stats.append([(1, "binary", b"x"), (40, "i64", 3)])                          # a field id that needs the long form
+    stats.append([(1, "binary", b"x"), (2, "i32", 3)])                           # a type Statistics does not hold
+    stats.append([])
+    chunks = []
+    for body in (0, 7, 64, 3000):
+        pages = []
+        for k, st in enumerate(stats):
+            if k % 3 == 0:
+                pages.append((H(0, body, body, data=(16, 0, 3, 3, st)), body))
+            elif k % 3 == 1:
+                pages.append((H(3, body, body, v2=(5, 1, 5, 0, 0, 0, bool(k & 2), st)), body))
+            else:
+                pages.append((H(3, body, body, v2=(5, 1, 5, 0, 0, 0, None, st)), body))
+        chunks.append(W.chunk(pages))
+        chunks.append(W.chunk(pages[::-1], max_def=1))
+    cut = []
+    for c in chunks[:2]:
+        for _ in range(60):
+            d = dict(c)
+            d["src"] = c["src"][: int(rng.integers(0, c["src"].size))].copy()
+            cut.append(d)
+    _compare(ctx, chunks + cut)
+    res, _ = _walk_all(ctx, chunks)
+    assert (res["status"] == 0).all() and (res["n_pages"] == len(stats)).all()
+
+
 @pytest.mark.parametrize("version,page_size", [("1.0", 1 << 30), ("2.0", 4000), ("1.0", 4000)])
 def test_pyarrow_file_end_to_end(ctx, tmp_path, version, page_size):
     import torch
