@@ -16,6 +16,7 @@
 //    Three launches: per tile of 2048 positions the summary {V_out, entries, values} for both
 //    possible V_in; one workgroup chains the tiles; the tiles then write their entries.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "pq_device.hpp"
 #include "pq_launch.hpp"
@@ -744,27 +745,35 @@ __global__ __launch_bounds__(WG) void entries_onepass_kernel(const int32_t *__re
     // an entry, and whether that entry has a value, is then the mask itself as the execution mask
     // or select mask, and the entries and values in front of the step are running scalar counts.
     uint32_t Ks = K, vbs = vb;
-    auto emit = [&](uint32_t s, int32_t dl) {
+    // Entries never outnumber positions: the bound only keeps a damaged summary from turning into a
+    // store outside the caller's arrays, and a tile whose entries all lie inside them (every tile
+    // of an undamaged column) does without it.  n < 2^30 on this path: byte offsets fit 32 bits,
+    // and the two stores share one (no 64-bit address arithmetic per entry).
+    auto emit = [&](uint32_t s, int32_t dl, auto bounded) {
         const uint64_t H = readlane_u64(my_h, s), v = readlane_u64(my_v, s);
         const bool head = __builtin_amdgcn_inverse_ballot_w64(H);
         const bool vbit = __builtin_amdgcn_inverse_ballot_w64(v);
         const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(H >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H, 0u));
         const uint32_t vr = __builtin_amdgcn_mbcnt_hi((uint32_t)(v >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)v, 0u));
         const uint32_t e = Ks + r;
-        // entries never outnumber positions: the bound only keeps a damaged summary from
-        // turning into a store outside the caller's arrays
-        if (head && e < n32) {
-            offsets[e] = vbs + vr;
-            entry_def[e] = vbit ? max_def : dl;
+        if (head && (!decltype(bounded)::value || e < n32)) {
+            const uint32_t at = e << 2;
+            *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(offsets) + at) = vbs + vr;
+            *reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(entry_def) + at) = vbit ? max_def : dl;
             vb8[shift + (e - K)] = vbit ? (uint8_t)1 : (uint8_t)0;
         }
         Ks += (uint32_t)__builtin_popcountll(H);
         vbs += (uint32_t)__builtin_popcountll(v);
     };
-    if (__builtin_amdgcn_ballot_w64((dbits >> 8) != 0u) == 0ull) {
+    if (__builtin_amdgcn_ballot_w64((dbits >> 8) != 0u) == 0ull && (uint64_t)K + tile_entries <= (uint64_t)n32) {
         // a whole tile whose levels were kept
 #pragma unroll
-        for (uint32_t s = 0; s < (uint32_t)kAsmSteps; ++s) emit(s, (int32_t)((dkeep[s >> 2] >> (8u * (s & 3u))) & 0xffu));
+        for (uint32_t s = 0; s < (uint32_t)kAsmSteps; ++s)
+            emit(s, (int32_t)((dkeep[s >> 2] >> (8u * (s & 3u))) & 0xffu), std::false_type{});
+    } else if (__builtin_amdgcn_ballot_w64((dbits >> 8) != 0u) == 0ull) {
+#pragma unroll
+        for (uint32_t s = 0; s < (uint32_t)kAsmSteps; ++s)
+            emit(s, (int32_t)((dkeep[s >> 2] >> (8u * (s & 3u))) & 0xffu), std::true_type{});
     } else {
         for (uint32_t s0 = 0; s0 < steps; s0 += 8) {
             int32_t dls[8];
@@ -777,7 +786,7 @@ __global__ __launch_bounds__(WG) void entries_onepass_kernel(const int32_t *__re
 #pragma unroll
             for (uint32_t j = 0; j < 8; ++j) {
                 if (s0 + j >= steps) break;
-                emit(s0 + j, dls[j]);
+                emit(s0 + j, dls[j], std::true_type{});
             }
         }
     }
