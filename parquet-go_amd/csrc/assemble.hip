@@ -704,7 +704,6 @@ __global__ __launch_bounds__(WG) void entries_onepass_kernel(const int32_t *__re
     my_v &= my_valid;
     const uint32_t hcnt = (uint32_t)__builtin_popcountll(my_h), vcnt = (uint32_t)__builtin_popcountll(my_v);
     const uint32_t tile_entries = wave_sum_u32(hcnt);
-    (void)vcnt;
     const uint32_t need = (uint32_t)__builtin_amdgcn_ballot_w64((my_h & ~my_v) != 0ull);
 
     const uint32_t n32 = (uint32_t)n;  // n < 2^30 on this path
@@ -743,27 +742,30 @@ __global__ __launch_bounds__(WG) void entries_onepass_kernel(const int32_t *__re
     const uint32_t shift = K & 31u;
     // A step's two masks come to the scalar side (four v_readlane); whether a lane's position opens
     // an entry, and whether that entry has a value, is then the mask itself as the execution mask
-    // or select mask, and the entries and values in front of the step are running scalar counts.
-    uint32_t Ks = K, vbs = vb;
+    // or select mask.  The entries and values in front of each step come from one scan over the
+    // tile's 32 steps (lane s: step s) and two more v_readlane a step.
+    const uint32_t e_before = K + wave_scan_u32(hcnt) - hcnt, v_before = vb + wave_scan_u32(vcnt) - vcnt;
+    int32_t level_of_values = max_def;
+    asm volatile("" : "+v"(level_of_values));  // in a vector register once, not moved there per step
     // Entries never outnumber positions: the bound only keeps a damaged summary from turning into a
     // store outside the caller's arrays, and a tile whose entries all lie inside them (every tile
     // of an undamaged column) does without it.  n < 2^30 on this path: byte offsets fit 32 bits,
     // and the two stores share one (no 64-bit address arithmetic per entry).
+    uint8_t *vb8e = vb8 + shift - K;  // entry e's validity byte (the sum is formed once, not per step)
     auto emit = [&](uint32_t s, int32_t dl, auto bounded) {
         const uint64_t H = readlane_u64(my_h, s), v = readlane_u64(my_v, s);
         const bool head = __builtin_amdgcn_inverse_ballot_w64(H);
         const bool vbit = __builtin_amdgcn_inverse_ballot_w64(v);
         const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(H >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H, 0u));
         const uint32_t vr = __builtin_amdgcn_mbcnt_hi((uint32_t)(v >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)v, 0u));
-        const uint32_t e = Ks + r;
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)e_before, (int)s) + r;
         if (head && (!decltype(bounded)::value || e < n32)) {
             const uint32_t at = e << 2;
-            *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(offsets) + at) = vbs + vr;
-            *reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(entry_def) + at) = vbit ? max_def : dl;
-            vb8[shift + (e - K)] = vbit ? (uint8_t)1 : (uint8_t)0;
+            *reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(offsets) + at) =
+                (uint32_t)__builtin_amdgcn_readlane((int)v_before, (int)s) + vr;
+            *reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(entry_def) + at) = vbit ? level_of_values : dl;
+            vb8e[e] = vbit ? (uint8_t)1 : (uint8_t)0;
         }
-        Ks += (uint32_t)__builtin_popcountll(H);
-        vbs += (uint32_t)__builtin_popcountll(v);
     };
     if (__builtin_amdgcn_ballot_w64((dbits >> 8) != 0u) == 0ull && (uint64_t)K + tile_entries <= (uint64_t)n32) {
         // a whole tile whose levels were kept
