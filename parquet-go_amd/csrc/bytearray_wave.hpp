@@ -503,7 +503,7 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
 #pragma unroll
         for (uint32_t u = 0; u < 3u; ++u) {
             const uint32_t q = (uint32_t)lane + kWave * u;
-            if (q < spieces) sv[u] = __builtin_nontemporal_load(s16 + q);
+            if (q < spieces) sv[u] = s16[q];
         }
         uint32_t n0, n1;
         int32_t np;
@@ -565,7 +565,7 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
             const uint32_t q = (uint32_t)lane + kWave * u;
             if (q < opieces) {
                 const u32x4_t v = *reinterpret_cast<const u32x4_t *>(obuf + ((dlow + f + 16u * q) & (kBaOutWin - 1u)));
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(data + f) + q);
+                reinterpret_cast<u32x4_t *>(data + f)[q] = v;
             }
         }
         f += 16u * opieces;
