@@ -301,7 +301,7 @@ __device__ __forceinline__ ByteArrayResult delta_length_ba_wave(uint32_t *window
 constexpr uint32_t kBaOutWin = 2048;           // bytes of the output a wave keeps in LDS (a power of two)
 constexpr uint32_t kBaSufWin = kBaOutWin + 16;  // a batch's suffix bytes, from a 16-byte boundary
 constexpr uint32_t kBaPrefixCols = 4;          // byte positions per step of the column loops: their LDS reads go
-constexpr uint32_t kBaCols = 8;                // out together, but every position of a step is paid for
+constexpr uint32_t kBaCols = 4;                // out together, but every position of a step is paid for
 constexpr uint32_t kBaLdsBytes = kBaOutWin + kBaSufWin;
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x)
