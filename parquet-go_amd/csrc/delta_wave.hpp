@@ -620,6 +620,120 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
                         delta_pair_loop<UT, OFFS>(lds, dst, o, p0, carry, st.need, lim,
                                                   tail ? 0x7fffffffu : (uint32_t)(kDwChunk - 2 * kDwBlockMax), stop_rel, wo, lane);
                 }
+                // one block behind its header: widths (a byte per miniblock), window offset of its data, minDelta
+                auto emit_block = [&](uint32_t widths, uint32_t data, int32_t md, uint32_t vl) {
+                        // every width <= 23 and a minDelta of at most three bytes: a tile's partial sums
+                        // fit 32 bits (see wave_decode_tile)
+                        const bool narrow = (((widths & 0x7f7f7f7fu) + 0x68686868u) & 0x80808080u) == 0u && vl <= 3u;
+#pragma unroll
+                        for (uint32_t tile = 0; tile < kTiles; ++tile) {
+                            // this tile's miniblocks: all four widths, or two of them
+                            const uint32_t tw = LG == 5u ? widths : (tile == 0u ? widths & 0xffffu : widths >> 16);
+                            const uint32_t bitbase = data * 8u + (tile == 0u ? 0u : 64u * (((widths & 0xffffu) * 0x0101u >> 8) & 0xffu));
+                            const uint32_t w = __builtin_amdgcn_ubfe(tw, ln.sh8, 8u);
+                            const uint32_t pre = __builtin_amdgcn_ubfe(tw * 0x01010100u, ln.sh8, 8u);
+                            const uint32_t bit = bitbase + (pre << LG) + ln.k2 * w;
+                            const uint32_t i = bit >> 5, sft = bit & 31u;
+                            const uint32_t e0 = lds[i], e1 = lds[i + 1], e2 = lds[i + 2];
+                            const uint32_t l32 = __builtin_amdgcn_alignbit(e1, e0, sft);
+                            const uint32_t h32 = __builtin_amdgcn_alignbit(e2, e1, sft);
+                            const uint32_t m = (uint32_t)(1ull << w) - 1u;
+                            const uint32_t ua = l32 & m;
+                            const uint32_t ub = (uint32_t)((((uint64_t)h32 << 32) | l32) >> w) & m;
+                            UT *const q = dst + p0 + 128u * tile + 2u * (uint32_t)lane;
+                            if constexpr (sizeof(UT) == 8) {
+                                UT v0, v1;
+                                if (narrow) {
+                                    const int32_t da = (int32_t)ua + md;
+                                    const int32_t pair = da + (int32_t)ub + md;
+                                    const int32_t incl = (int32_t)wave_scan_u32((uint32_t)pair);
+                                    v0 = carry + (UT)(int64_t)(incl - pair);
+                                    v1 = v0 + (UT)(int64_t)da;
+                                    carry += (UT)(int64_t)(int32_t)wave_last_u32((uint32_t)incl);
+                                } else {
+                                    const UT a = (UT)ua + (UT)(int64_t)md;
+                                    const UT pair = a + (UT)ub + (UT)(int64_t)md;
+                                    const UT incl = wave_scan_u64(pair);
+                                    v0 = carry + (incl - pair);
+                                    v1 = v0 + a;
+                                    carry += wave_last_u64(incl);
+                                }
+                                if (vec_ok) {
+                                    store_nt16(q, (uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32));
+                                } else {
+                                    q[0] = v0;
+                                    q[1] = v1;
+                                }
+                            } else {
+                                const UT a = ua + (UT)md;
+                                const UT pair = a + ub + (UT)md;
+                                const UT incl = wave_scan_u32(pair);
+                                UT v0 = carry + (incl - pair);
+                                UT v1 = v0 + a;
+                                carry += wave_last_u32(incl);
+                                if constexpr (OFFS) {
+                                    // the values are lengths: what is stored is the sum of those in front
+                                    const uint32_t l0 = v0, both = v0 + v1;
+                                    const uint32_t oincl = wave_scan_u32(both);
+                                    wo->big |= __builtin_amdgcn_ballot_w64((v0 | v1) >= (1u << 24)) != 0ull ? 1u : 0u;
+                                    v0 = wo->sum + (oincl - both);
+                                    v1 = v0 + l0;
+                                    wo->sum += wave_last_u32(oincl);
+                                    wo->big |= wo->sum >> 31;
+                                }
+                                if (vec_ok) {
+                                    store_nt8(q, v0, v1);
+                                } else {
+                                    q[0] = v0;
+                                    q[1] = v1;
+                                }
+                            }
+                        }
+                };
+                if constexpr (LG == 5u && sizeof(UT) == 8) {
+                    // Two blocks an iteration: the lower half of the wave reads the first header, the upper
+                    // half the second (which starts where the first says), all in vector registers; what
+                    // the decode wants as scalars comes over with a handful of v_readlane.  The same
+                    // walk on the scalar unit, one header at a time, was more than half of a block's
+                    // instructions.
+                    const bool upper = lane >= 32;
+                    const uint32_t o_max2 = tail ? 0x7fffffffu : (uint32_t)(kDwChunk - 2 * kDwBlockMax);
+                    while (o <= o_max2 && p0 + 256u < st.need && (int32_t)o < stop_rel) {
+                        uint32_t next_a;
+                        {
+                            const uint32_t k = o >> 2;
+                            const uint32_t d0 = lds[k], d1 = lds[k + 1], d2 = lds[k + 2];
+                            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, o * 8u);
+                            const uint32_t mid = __builtin_amdgcn_alignbit(d2, d1, o * 8u);
+                            const uint32_t end = ~lo & 0x80808080u;
+                            const uint32_t vl = ((uint32_t)__builtin_ctz(end | 0x80000000u) + 1u) >> 3;
+                            const uint32_t widths = (uint32_t)(((((uint64_t)mid) << 32) | lo) >> (8u * vl));
+                            next_a = o + vl + 4u + 4u * __builtin_amdgcn_sad_u8(widths, 0u, 0u);
+                        }
+                        // a first header that is not a plain one sends the second half anywhere: keep its reads inside the window
+                        const uint32_t ho = upper ? min(next_a, (uint32_t)kDwChunk) : o;
+                        const uint32_t k = ho >> 2;
+                        const uint32_t d0 = lds[k], d1 = lds[k + 1], d2 = lds[k + 2];
+                        const uint32_t hdr_lo = __builtin_amdgcn_alignbit(d1, d0, ho * 8u);
+                        const uint32_t mid = __builtin_amdgcn_alignbit(d2, d1, ho * 8u);
+                        const uint32_t end = ~hdr_lo & 0x80808080u;
+                        const uint32_t vl = ((uint32_t)__builtin_ctz(end | 0x80000000u) + 1u) >> 3;  // 1..4
+                        const uint32_t widths = (uint32_t)(((((uint64_t)mid) << 32) | hdr_lo) >> (8u * vl));
+                        const uint32_t data = ho + vl + 4u;
+                        const uint32_t next = data + 4u * __builtin_amdgcn_sad_u8(widths, 0u, 0u);
+                        const bool bad = end == 0u || ((((widths & 0x7f7f7f7fu) + 0x5f5f5f5fu) | widths) & 0x80808080u) != 0u ||
+                                         next > lim || (upper && (int32_t)next_a >= stop_rel);
+                        if (__builtin_amdgcn_ballot_w64(bad) != 0ull) break;
+                        const int32_t md = wave_expand_min_delta(hdr_lo, vl);
+                        emit_block((uint32_t)__builtin_amdgcn_readlane((int)widths, 0), (uint32_t)__builtin_amdgcn_readlane((int)data, 0),
+                                   __builtin_amdgcn_readlane(md, 0), (uint32_t)__builtin_amdgcn_readlane((int)vl, 0));
+                        p0 += 128u;
+                        emit_block((uint32_t)__builtin_amdgcn_readlane((int)widths, 32), (uint32_t)__builtin_amdgcn_readlane((int)data, 32),
+                                   __builtin_amdgcn_readlane(md, 32), (uint32_t)__builtin_amdgcn_readlane((int)vl, 32));
+                        p0 += 128u;
+                        o = (uint32_t)__builtin_amdgcn_readlane((int)next, 32);
+                    }
+                }
                 while (o <= o_max && p0 + kBlockValues < st.need && (int32_t)o < stop_rel && (LG == 5u || blk.half == 0u)) {
                     const uint32_t k = o >> 2, sh = (o & 3u) * 8u;
                     const uint32_t h0 = uni(lds[k]), h1 = uni(lds[k + 1]), h2 = uni(lds[k + 2]);
@@ -634,73 +748,7 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
                     if (end == 0u || ((((widths & 0x7f7f7f7fu) + 0x5f5f5f5fu) | widths) & 0x80808080u) != 0u || next > lim)
                         break;
                     const int32_t md = wave_expand_min_delta(hdr_lo, vl);
-                    // every width <= 23 and a minDelta of at most three bytes: a tile's partial sums
-                    // fit 32 bits (see wave_decode_tile)
-                    const bool narrow = (((widths & 0x7f7f7f7fu) + 0x68686868u) & 0x80808080u) == 0u && vl <= 3u;
-#pragma unroll
-                    for (uint32_t tile = 0; tile < kTiles; ++tile) {
-                        // this tile's miniblocks: all four widths, or two of them
-                        const uint32_t tw = LG == 5u ? widths : (tile == 0u ? widths & 0xffffu : widths >> 16);
-                        const uint32_t bitbase = data * 8u + (tile == 0u ? 0u : 64u * (((widths & 0xffffu) * 0x0101u >> 8) & 0xffu));
-                        const uint32_t w = __builtin_amdgcn_ubfe(tw, ln.sh8, 8u);
-                        const uint32_t pre = __builtin_amdgcn_ubfe(tw * 0x01010100u, ln.sh8, 8u);
-                        const uint32_t bit = bitbase + (pre << LG) + ln.k2 * w;
-                        const uint32_t i = bit >> 5, sft = bit & 31u;
-                        const uint32_t e0 = lds[i], e1 = lds[i + 1], e2 = lds[i + 2];
-                        const uint32_t l32 = __builtin_amdgcn_alignbit(e1, e0, sft);
-                        const uint32_t h32 = __builtin_amdgcn_alignbit(e2, e1, sft);
-                        const uint32_t m = (uint32_t)(1ull << w) - 1u;
-                        const uint32_t ua = l32 & m;
-                        const uint32_t ub = (uint32_t)((((uint64_t)h32 << 32) | l32) >> w) & m;
-                        UT *const q = dst + p0 + 128u * tile + 2u * (uint32_t)lane;
-                        if constexpr (sizeof(UT) == 8) {
-                            UT v0, v1;
-                            if (narrow) {
-                                const int32_t da = (int32_t)ua + md;
-                                const int32_t pair = da + (int32_t)ub + md;
-                                const int32_t incl = (int32_t)wave_scan_u32((uint32_t)pair);
-                                v0 = carry + (UT)(int64_t)(incl - pair);
-                                v1 = v0 + (UT)(int64_t)da;
-                                carry += (UT)(int64_t)(int32_t)wave_last_u32((uint32_t)incl);
-                            } else {
-                                const UT a = (UT)ua + (UT)(int64_t)md;
-                                const UT pair = a + (UT)ub + (UT)(int64_t)md;
-                                const UT incl = wave_scan_u64(pair);
-                                v0 = carry + (incl - pair);
-                                v1 = v0 + a;
-                                carry += wave_last_u64(incl);
-                            }
-                            if (vec_ok) {
-                                store_nt16(q, (uint32_t)v0, (uint32_t)(v0 >> 32), (uint32_t)v1, (uint32_t)(v1 >> 32));
-                            } else {
-                                q[0] = v0;
-                                q[1] = v1;
-                            }
-                        } else {
-                            const UT a = ua + (UT)md;
-                            const UT pair = a + ub + (UT)md;
-                            const UT incl = wave_scan_u32(pair);
-                            UT v0 = carry + (incl - pair);
-                            UT v1 = v0 + a;
-                            carry += wave_last_u32(incl);
-                            if constexpr (OFFS) {
-                                // the values are lengths: what is stored is the sum of those in front
-                                const uint32_t l0 = v0, both = v0 + v1;
-                                const uint32_t oincl = wave_scan_u32(both);
-                                wo->big |= __builtin_amdgcn_ballot_w64((v0 | v1) >= (1u << 24)) != 0ull ? 1u : 0u;
-                                v0 = wo->sum + (oincl - both);
-                                v1 = v0 + l0;
-                                wo->sum += wave_last_u32(oincl);
-                                wo->big |= wo->sum >> 31;
-                            }
-                            if (vec_ok) {
-                                store_nt8(q, v0, v1);
-                            } else {
-                                q[0] = v0;
-                                q[1] = v1;
-                            }
-                        }
-                    }
+                    emit_block(widths, data, md, vl);
                     o = next;
                     p0 += kBlockValues;
                 }
