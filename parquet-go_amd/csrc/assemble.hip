@@ -19,6 +19,8 @@
 #include <type_traits>
 
 #include "pq_device.hpp"
+#include <mutex>
+
 #include "pq_launch.hpp"
 
 namespace pq {
@@ -893,6 +895,24 @@ size_t entries_workspace_bytes(uint64_t n)
     return (size_t)(tiles * kAsmSteps * 16 + tiles * 32 + groups * 32);
 }
 
+// Zeroes two ranges of 32-bit words in one launch.  A kernel rather than hipMemsetAsync: a caller
+// may record these launches into a HIP graph, and memset nodes are not safe to replay there.
+__global__ __launch_bounds__(256) void entries_clear_kernel(uint32_t *__restrict__ a, uint64_t na,
+                                                            uint32_t *__restrict__ b, uint64_t nb)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < na; i += stride) a[i] = 0u;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < nb; i += stride) b[i] = 0u;
+}
+
+static void launch_entries_clear(hipStream_t s, uint32_t *a, uint64_t na, uint32_t *b, uint64_t nb)
+{
+    const uint64_t most = na > nb ? na : nb;
+    if (most == 0) return;
+    const uint64_t blocks = (most + 1023) / 1024;  // four words a thread
+    hipLaunchKernelGGL(entries_clear_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, a, na, b, nb);
+}
+
 hipError_t launch_column_entries(hipStream_t s, const int32_t *d_def, const int32_t *d_rep, uint64_t n,
                                  int32_t max_def, int32_t max_rep, int repeated, uint32_t *d_offsets,
                                  uint32_t *d_validity, int32_t *d_entry_def, pq_entries_result *d_result,
@@ -903,20 +923,19 @@ hipError_t launch_column_entries(hipStream_t s, const int32_t *d_def, const int3
     uint64_t *masks = reinterpret_cast<uint64_t *>(d_work);
     uint32_t *tile_sum = reinterpret_cast<uint32_t *>(masks + tiles * kAsmSteps * 2);
     uint32_t *group_sum = tile_sum + tiles * 8;
-    hipError_t e = hipMemsetAsync(d_validity, 0, (size_t)((n + 31) / 32 * 4), s);
-    if (e != hipSuccess) return e;
+    const uint64_t validity_words = (n + 31) / 32;
     if (groups != 0 && n < kOnePassMaxN) {
         // one launch: the group records (two 64-bit words per group) start at zero.  Groups of
         // kOnePassWG / 64 tiles.  (Groups of 16 tiles instead of 4, to have fewer records to look
         // back over, were no faster: the time is in the vector instructions of the write phase.)
         const uint64_t big = (tiles + kOnePassWG / kWave - 1) / (kOnePassWG / kWave);
         uint64_t *agg = reinterpret_cast<uint64_t *>(d_work);
-        e = hipMemsetAsync(agg, 0, (size_t)(big * 16), s);
-        if (e != hipSuccess) return e;
+        launch_entries_clear(s, d_validity, validity_words, reinterpret_cast<uint32_t *>(agg), big * 4);
         hipLaunchKernelGGL(entries_onepass_kernel<kOnePassWG>, dim3((unsigned)big), dim3(kOnePassWG), 0, s, d_def, d_rep,
                            n, max_def, max_rep, repeated, agg, agg + big, big, d_offsets, d_validity, d_entry_def, d_result);
         return hipGetLastError();
     }
+    launch_entries_clear(s, d_validity, validity_words, nullptr, 0);
     if (groups != 0)
         hipLaunchKernelGGL(entries_summary_kernel, dim3((unsigned)groups), dim3(kAsmWG), 0, s, d_def, d_rep, n, max_def,
                            max_rep, repeated, masks, tile_sum, group_sum);
@@ -928,31 +947,50 @@ hipError_t launch_column_entries(hipStream_t s, const int32_t *d_def, const int3
 }
 
 // ---- column entries without any allocation ---------------------------------------------------
-// The same three launches over a workspace that is part of the library's device image: a
-// file-scope device array, one copy per GPU, held until the process ends.  In host code the
-// array's name is only a stand-in for the symbol; the device address comes from
-// hipGetSymbolAddress, asked once per device (static_scratch_init, called when a context is
-// created on the device) and kept in g_scratch[device].
+// The same launches over a workspace that is part of the library's device image: a file-scope
+// device array, one copy per GPU, held until the process ends.  In host code the array's name is
+// only a stand-in for the symbol; the device address comes from hipGetSymbolAddress, asked once
+// per device (static_scratch_init, called when a context is created on the device) and kept in
+// g_dev[device].
+//
+// Every context and stream of a GPU shares the one array, and the one-pass kernel's workgroups wait
+// on the records in it: a second call that cleared them under a running first call would leave the
+// first one's workgroups waiting for good.  So the calls of a GPU are put in order here: each call
+// makes its stream wait for an event recorded behind the call before it (on whatever stream that
+// was) and records the event again behind itself, all under the device's mutex.  Waiting on and
+// recording an event allocate nothing.  A stream that is being captured into a graph is left
+// alone (an event recorded outside a capture cannot be waited for inside one): the launches it
+// records are ordered by the graph, and keeping a replay apart from other calls on the GPU is the
+// caller's business.
 constexpr size_t kStaticScratchBytes = 8u << 20;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 constexpr int kMaxDevices = 64;
-static void *g_scratch[kMaxDevices];          // device address of `scratch` on each GPU (null: not asked yet)
-static hipError_t g_scratch_err[kMaxDevices];  // why it is null after asking
+struct ScratchDevice {
+    std::mutex m;
+    void *ptr = nullptr;             // device address of `scratch` on this GPU (null: not asked yet)
+    hipError_t err = hipSuccess;     // why it is null after asking
+    hipEvent_t last = nullptr;       // recorded behind the most recent call
+    hipStream_t last_stream = nullptr;
+    bool recorded = false;
+};
+static ScratchDevice g_dev[kMaxDevices];
 
 size_t static_scratch_bytes() { return kStaticScratchBytes; }
 
-// Once per device, with that device current.  Not thread-safe against itself for one device: the
-// caller (pq_ctx_create) serialises.
+// Once per device, with that device current.
 hipError_t static_scratch_init(int device)
 {
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
-    if (g_scratch[device]) return hipSuccess;
+    ScratchDevice &D = g_dev[device];
+    std::lock_guard<std::mutex> lock(D.m);
+    if (D.ptr) return hipSuccess;
     void *ptr = nullptr;
-    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
-    g_scratch_err[device] = e;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e == hipSuccess && !D.last) e = hipEventCreateWithFlags(&D.last, hipEventDisableTiming);
+    D.err = e;
     if (e != hipSuccess) return e;
-    g_scratch[device] = ptr;
+    D.ptr = ptr;
     return hipSuccess;
 }
 
@@ -962,12 +1000,25 @@ hipError_t launch_column_entries_static(int device, hipStream_t s, const int32_t
                                         pq_entries_result *d_result)
 {
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
-    void *ptr = g_scratch[device];
-    if (!ptr) return g_scratch_err[device] != hipSuccess ? g_scratch_err[device] : hipErrorNotInitialized;
     if (entries_workspace_bytes(n) > kStaticScratchBytes) return hipErrorInvalidValue;
+    ScratchDevice &D = g_dev[device];
+    std::lock_guard<std::mutex> lock(D.m);
+    if (!D.ptr) return D.err != hipSuccess ? D.err : hipErrorNotInitialized;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    hipError_t e = hipSuccess;
+    if (!capturing && D.recorded && D.last_stream != s) e = hipStreamWaitEvent(s, D.last, 0);
+    if (e != hipSuccess) return e;
     // the launcher clears the words of the workspace that have to start at zero
-    return launch_column_entries(s, d_def, d_rep, n, max_def, max_rep, repeated, d_offsets, d_validity, d_entry_def,
-                                 d_result, ptr);
+    e = launch_column_entries(s, d_def, d_rep, n, max_def, max_rep, repeated, d_offsets, d_validity, d_entry_def,
+                              d_result, D.ptr);
+    if (e != hipSuccess || capturing) return e;
+    e = hipEventRecord(D.last, s);
+    if (e == hipSuccess) {
+        D.recorded = true;
+        D.last_stream = s;
+    }
+    return e;
 }
 
 }  // namespace pq

@@ -100,6 +100,11 @@ struct pq_plan {
     pq::HsegPage *d_hseg_pages = nullptr;
     uint32_t *d_hseg_seg_owner = nullptr, *d_hseg_check_owner = nullptr, *d_hseg_counts = nullptr;
     pq::HsegRec *d_hseg_recs = nullptr;
+    // data pages of flat columns that are decoded as the value streams they hold (see lower_flat_page):
+    // their ids, and whether any of them wants its constant levels written out
+    uint32_t n_lowered = 0;
+    uint32_t *d_lowered = nullptr;
+    bool lowered_levels = false;
 };
 
 namespace {
@@ -170,8 +175,43 @@ uint32_t value_size(const pq_page_desc &d)
     }
 }
 
+// A data page of a flat column is its value stream: with max_rep == 0 both level decoders are
+// ConstDecoder(0) and read nothing (layout/chunk.go:111-124), the V1 block starts with the values
+// (page-v1.go:69-77 initialises the constant decoders on it without consuming a byte), the V2
+// values start behind the level bytes the header announces (page-v2.go:81-110), and with
+// max_def == 0 every slot is a value (layout/helpers.go:84-86).  Such a page is decoded by the
+// kernels of its value encoding — which cut large pages into segments — and a last small kernel
+// turns the stream's result into the page's (page-v1.go:80-116).  Pages that decode no value
+// (max_def != 0: the constant level 0 never equals it), empty pages and V2 pages whose level bytes
+// are not all there stay with the page kernels.
+constexpr uint32_t kFlagLowered = 0x80000000u;  // internal: never set by callers (validate refuses it)
+
+bool lower_flat_page(pq_page_desc &d)
+{
+    if (d.kind != PQ_KIND_PAGE_V1 && d.kind != PQ_KIND_PAGE_V2) return false;
+    if (d.max_rep != 0 || d.max_def != 0 || d.n_values == 0) return false;
+    switch (d.value_kind) {
+    case PQ_KIND_DICT:
+    case PQ_KIND_DELTA32:
+    case PQ_KIND_DELTA64:
+    case PQ_KIND_PLAIN:
+    case PQ_KIND_BOOL_PLAIN:
+    case PQ_KIND_BOOL_RLE: break;
+    default: return false;  // byte arrays have page kernels of their own
+    }
+    const uint64_t vpos = d.kind == PQ_KIND_PAGE_V2 ? (uint64_t)d.rep_len + d.def_len : 0u;
+    if (vpos > d.src_len) return false;
+    d.kind = d.value_kind;
+    d.src_off += vpos;
+    d.src_len -= vpos;
+    d.flags = (d.flags & PQ_FLAG_NO_LEVEL_OUTPUT) | kFlagLowered;
+    return true;
+}
+
 int validate(const pq_page_desc &d)
 {
+    if (d.flags & ~(uint32_t)(PQ_FLAG_LENGTH_PREFIXED | PQ_FLAG_LEVELS_CONST | PQ_FLAG_NO_INIT | PQ_FLAG_NO_LEVEL_OUTPUT))
+        return PQ_ERR_BAD_ARGUMENT;
     if (kind_group(d.kind) < 0) return PQ_ERR_BAD_ARGUMENT;
     if (d.n_values > 0x7fffffffu) return PQ_ERR_BAD_ARGUMENT; // counts are int32 in the reference
     if (d.src_len > 0x7fffffffffffull) return PQ_ERR_BAD_ARGUMENT;
@@ -441,9 +481,9 @@ int pq_bitunpack64(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, size_
 
 // ---- plans ------------------------------------------------------------------
 
-int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_plan **out)
+int pq_plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pages, pq_plan **out)
 {
-    if (!ctx || !out || (n_pages && !descs) || n_pages > 0x7fffffffu) return PQ_ERR_BAD_ARGUMENT;
+    if (!ctx || !out || (n_pages && !user_descs) || n_pages > 0x7fffffffu) return PQ_ERR_BAD_ARGUMENT;
     *out = nullptr;
     std::vector<uint32_t> ids[kGroups];
     pq_plan *plan = new (std::nothrow) pq_plan;
@@ -453,18 +493,18 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
     uint64_t dict_bytes_max = 0;
     bool dict_seen = false, dict_shared = true;
     uint64_t dict0_off = 0, dict0_bytes = 0;
+    // the table the kernels see: the caller's, with the pages of flat columns turned into the value
+    // streams they are
+    std::vector<pq_page_desc> descs(user_descs, user_descs + n_pages);
+    std::vector<uint32_t> lowered;
     for (size_t i = 0; i < n_pages; ++i) {
-        const pq_page_desc &d = descs[i];
+        const pq_page_desc &d = user_descs[i];
         const int st = validate(d);
         if (st != PQ_OK) {
             delete plan;
             return st;
         }
-        ids[group_of(d)].push_back((uint32_t)i);
         plan->src_need = std::max(plan->src_need, d.src_off + d.src_len);
-        if ((d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2) &&
-            (d.value_kind == PQ_KIND_DELTA32 || d.value_kind == PQ_KIND_DELTA64))
-            plan->has_delta_page = true;
         const uint32_t vs = value_size(d);
         if (vs) plan->values_need = std::max(plan->values_need, d.dst_off + (uint64_t)d.n_values * vs);
         const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
@@ -491,7 +531,17 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
                 dict_shared = false;
             }
         }
+        if (lower_flat_page(descs[i])) {
+            lowered.push_back((uint32_t)i);
+            if (!no_levels) plan->lowered_levels = true;
+        }
+        const pq_page_desc &t = descs[i];
+        ids[group_of(t)].push_back((uint32_t)i);
+        if ((t.kind == PQ_KIND_PAGE_V1 || t.kind == PQ_KIND_PAGE_V2) &&
+            (t.value_kind == PQ_KIND_DELTA32 || t.value_kind == PQ_KIND_DELTA64))
+            plan->has_delta_page = true;
     }
+    plan->n_lowered = (uint32_t)lowered.size();
     plan->dict_lds_bytes = (uint32_t)((dict_bytes_max + 15u) & ~15ull);
     if (dict_seen && dict_shared && dict0_bytes != 0 && dict0_bytes <= pq::kDictLdsMax) {
         plan->shared_dict_bytes = (uint32_t)dict0_bytes;
@@ -568,8 +618,8 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
         }
         auto cut = [&](uint32_t i) {
             const pq_page_desc &d = descs[i];
-            return (d.kind == PQ_KIND_DICT || (d.kind == PQ_KIND_HYBRID && d.flags == 0u)) && d.src_len >= 3 * L &&
-                   d.src_len < 0x7fffffffull && d.n_values >= 4096u;
+            const bool raw = d.kind == PQ_KIND_HYBRID && d.flags == 0u;
+            return (d.kind == PQ_KIND_DICT || raw) && d.src_len >= 3 * L && d.src_len < 0x7fffffffull && d.n_values >= 4096u;
         };
         std::stable_partition(g.begin(), g.end(), [&](uint32_t i) { return !cut(i); });
         for (uint32_t i : g) {
@@ -598,24 +648,39 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
         all.insert(all.end(), ids[g].begin(), ids[g].end());
     }
     if (n_pages) {
-        // one block: descriptors | ids | wake-up words (uint32 [0], [32], [64], each on a 128-byte
-        // line of its own) | segment page records and segment -> page maps | results | segment
-        // records.  Everything in front of the results is put together in a pinned host image and
-        // goes over in one copy.
-        constexpr size_t kFlagBytes = 512;
+        // One device block.  In front what the host fills — descriptors | ids | wake-up words
+        // (uint32 [0], [32], [64], each on a 128-byte line of its own) | segment page records and
+        // segment -> page maps | ids of the lowered pages — put together in a pinned host image
+        // and sent in one copy; behind it what the device writes: results | segment records.
+        struct Region {
+            size_t at, bytes;
+        };
+        size_t img = 0;
         auto up = [](size_t x) { return (x + 255) / 256 * 256; };
-        const size_t db = up(n_pages * sizeof(pq_page_desc)), rb = up(n_pages * sizeof(pq_page_result));
-        const size_t ib = up(n_pages * sizeof(uint32_t));
-        size_t spb[2], sob[2], srb[2];
+        auto take = [&](size_t bytes) {
+            Region r{img, bytes};
+            img += up(bytes);
+            return r;
+        };
+        constexpr size_t kFlagBytes = 512;
+        const Region r_descs = take(n_pages * sizeof(pq_page_desc)), r_ids = take(n_pages * sizeof(uint32_t));
+        const Region r_flags = take(kFlagBytes);
+        Region r_sp[2], r_so[2];
         for (int k = 0; k < 2; ++k) {
-            spb[k] = up(seg_pages[k].size() * sizeof(pq::SegPage));
-            sob[k] = up(seg_owner[k].size() * sizeof(uint32_t));
-            srb[k] = up(seg_owner[k].size() * sizeof(pq::SegRec));
+            r_sp[k] = take(seg_pages[k].size() * sizeof(pq::SegPage));
+            r_so[k] = take(seg_owner[k].size() * sizeof(uint32_t));
         }
-        const size_t hpb = up(hseg_pages.size() * sizeof(pq::HsegPage)), hsb = up(hseg_seg_owner.size() * sizeof(uint32_t));
-        const size_t hcb = up(hseg_check_owner.size() * sizeof(uint32_t)), hrb = up(hseg_seg_owner.size() * sizeof(pq::HsegRec));
-        const size_t img = db + ib + kFlagBytes + spb[0] + sob[0] + spb[1] + sob[1] + hpb + hsb + hcb;
-        const size_t total = img + rb + srb[0] + srb[1] + hrb + hcb;
+        const Region r_hp = take(hseg_pages.size() * sizeof(pq::HsegPage));
+        const Region r_hs = take(hseg_seg_owner.size() * sizeof(uint32_t));
+        const Region r_hc = take(hseg_check_owner.size() * sizeof(uint32_t));
+        const Region r_low = take(lowered.size() * sizeof(uint32_t));
+        const size_t img_bytes = img;
+        const Region r_res = take(n_pages * sizeof(pq_page_result));
+        Region r_sr[2];
+        for (int k = 0; k < 2; ++k) r_sr[k] = take(seg_owner[k].size() * sizeof(pq::SegRec));
+        const Region r_hr = take(hseg_seg_owner.size() * sizeof(pq::HsegRec));
+        const Region r_hn = take(hseg_check_owner.size() * sizeof(uint32_t));
+        const size_t total = img;
         uint8_t *block = nullptr;
         hipError_t e = hipSuccess;
         if (ctx->spare_block && ctx->spare_bytes >= total) {
@@ -632,47 +697,44 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_pl
             e = hipEventCreateWithFlags(&ctx->host_img_done[slot], hipEventDisableTiming);
         // the copy of the plan before last came out of this image: it has to be over
         if (e == hipSuccess) e = hipEventSynchronize(ctx->host_img_done[slot]);
-        if (e == hipSuccess && ctx->host_img_cap[slot] < img) {
+        if (e == hipSuccess && ctx->host_img_cap[slot] < img_bytes) {
             if (ctx->host_img[slot]) (void)hipHostFree(ctx->host_img[slot]);
             ctx->host_img[slot] = nullptr;
             ctx->host_img_cap[slot] = 0;
-            const size_t cap = img + img / 2;
+            const size_t cap = img_bytes + img_bytes / 2;
             e = hipHostMalloc(&ctx->host_img[slot], cap, hipHostMallocDefault);
             if (e == hipSuccess) ctx->host_img_cap[slot] = cap;
         }
         if (e == hipSuccess) {
-            plan->d_descs = reinterpret_cast<pq_page_desc *>(block);
-            plan->d_ids = reinterpret_cast<uint32_t *>(block + db);
-            plan->d_flags = reinterpret_cast<uint32_t *>(block + db + ib);
-            plan->d_results = reinterpret_cast<pq_page_result *>(block + img);
             uint8_t *h = static_cast<uint8_t *>(ctx->host_img[slot]);
-            std::memcpy(h, descs, n_pages * sizeof(pq_page_desc));
-            std::memcpy(h + db, all.data(), n_pages * sizeof(uint32_t));
-            std::memset(h + db + n_pages * sizeof(uint32_t), 0, ib - n_pages * sizeof(uint32_t) + kFlagBytes);
-            size_t at = db + ib + kFlagBytes, rec_at = img + rb;
+            auto put = [&](const Region &r, const void *p) {
+                if (r.bytes) std::memcpy(h + r.at, p, r.bytes);
+            };
+            plan->d_descs = reinterpret_cast<pq_page_desc *>(block + r_descs.at);
+            plan->d_ids = reinterpret_cast<uint32_t *>(block + r_ids.at);
+            plan->d_flags = reinterpret_cast<uint32_t *>(block + r_flags.at);
+            plan->d_results = reinterpret_cast<pq_page_result *>(block + r_res.at);
+            put(r_descs, descs.data());
+            put(r_ids, all.data());
+            std::memset(h + r_flags.at, 0, kFlagBytes);
             for (int k = 0; k < 2; ++k) {
-                plan->d_seg_pages[k] = reinterpret_cast<pq::SegPage *>(block + at);
-                if (!seg_pages[k].empty()) std::memcpy(h + at, seg_pages[k].data(), seg_pages[k].size() * sizeof(pq::SegPage));
-                at += spb[k];
-                plan->d_seg_owner[k] = reinterpret_cast<uint32_t *>(block + at);
-                if (!seg_owner[k].empty()) std::memcpy(h + at, seg_owner[k].data(), seg_owner[k].size() * sizeof(uint32_t));
-                at += sob[k];
-                plan->d_seg_recs[k] = reinterpret_cast<pq::SegRec *>(block + rec_at);
-                rec_at += srb[k];
+                plan->d_seg_pages[k] = reinterpret_cast<pq::SegPage *>(block + r_sp[k].at);
+                plan->d_seg_owner[k] = reinterpret_cast<uint32_t *>(block + r_so[k].at);
+                plan->d_seg_recs[k] = reinterpret_cast<pq::SegRec *>(block + r_sr[k].at);
+                put(r_sp[k], seg_pages[k].data());
+                put(r_so[k], seg_owner[k].data());
             }
-            plan->d_hseg_pages = reinterpret_cast<pq::HsegPage *>(block + at);
-            if (!hseg_pages.empty()) std::memcpy(h + at, hseg_pages.data(), hseg_pages.size() * sizeof(pq::HsegPage));
-            at += hpb;
-            plan->d_hseg_seg_owner = reinterpret_cast<uint32_t *>(block + at);
-            if (!hseg_seg_owner.empty()) std::memcpy(h + at, hseg_seg_owner.data(), hseg_seg_owner.size() * sizeof(uint32_t));
-            at += hsb;
-            plan->d_hseg_check_owner = reinterpret_cast<uint32_t *>(block + at);
-            if (!hseg_check_owner.empty())
-                std::memcpy(h + at, hseg_check_owner.data(), hseg_check_owner.size() * sizeof(uint32_t));
-            at += hcb;
-            plan->d_hseg_recs = reinterpret_cast<pq::HsegRec *>(block + rec_at);
-            plan->d_hseg_counts = reinterpret_cast<uint32_t *>(block + rec_at + hrb);
-            e = hipMemcpyAsync(block, h, img, hipMemcpyHostToDevice, ctx->stream);
+            plan->d_hseg_pages = reinterpret_cast<pq::HsegPage *>(block + r_hp.at);
+            plan->d_hseg_seg_owner = reinterpret_cast<uint32_t *>(block + r_hs.at);
+            plan->d_hseg_check_owner = reinterpret_cast<uint32_t *>(block + r_hc.at);
+            plan->d_hseg_recs = reinterpret_cast<pq::HsegRec *>(block + r_hr.at);
+            plan->d_hseg_counts = reinterpret_cast<uint32_t *>(block + r_hn.at);
+            plan->d_lowered = reinterpret_cast<uint32_t *>(block + r_low.at);
+            put(r_hp, hseg_pages.data());
+            put(r_hs, hseg_seg_owner.data());
+            put(r_hc, hseg_check_owner.data());
+            put(r_low, lowered.data());
+            e = hipMemcpyAsync(block, h, img_bytes, hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess) e = hipEventRecord(ctx->host_img_done[slot], ctx->stream);
         } else if (block) {
             plan->d_descs = reinterpret_cast<pq_page_desc *>(block);  // for pq_plan_destroy
@@ -770,6 +832,9 @@ int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_valu
         PQ_HIP(ctx, pq::launch_delta_serial(ctx->stream, plan->d_descs, plan->d_ids + plan->first[1],
                                             plan->count[1] + plan->count[2] + plan->count[3], buf,
                                             plan->d_results));
+    // pages of flat columns that ran as their value streams: the stream's result becomes the page's
+    PQ_HIP(ctx, pq::launch_lowered_finish(ctx->stream, plan->d_descs, plan->d_lowered, plan->n_lowered, buf,
+                                          plan->d_results, plan->lowered_levels));
     return PQ_OK;
 }
 

@@ -219,6 +219,7 @@ __global__ __launch_bounds__(kWG) void stream_pages_kernel(const pq_page_desc *_
             if (flags & PQ_FLAG_LENGTH_PREFIXED) sec = section_init_size(S, len, w);
             if (sec.init_status != PQ_OK) {
                 r.status = sec.init_status;
+                if (brle) extra = PQ_STAGE_VALUES_INIT;  // BooleanRLEDecoder.Init failed, not DecodeValues
             } else if (levels) {
                 r = run_section<HY_LEVELS, uint32_t>(sh, sec, w, n, dst, nullptr, 0, d.max_def);
                 // decodePackedArray returns (nil, 0, err) on any error (layout/helpers.go:78-80)
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(kWG) void stream_pages_kernel(const pq_page_desc *_
                                       reinterpret_cast<const uint32_t *>(gd),
                                       reinterpret_cast<const uint32_t *>(ldict), in_lds, d.dict_len,
                                       &init_status);
-        (void)init_status;
+        if (init_status != PQ_OK) extra = PQ_STAGE_VALUES_INIT;  // DictDecoder.Init failed
     }
     if (threadIdx.x == 0) {
         pq_page_result out;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(kWG) void delta_pages_kernel(const pq_page_desc *__
             if (SWEEP && r.status == kNeedSerial) r = delta_serial<UT>(S, (int64_t)d.src_len, d.n_values, dst);
             pq_page_result out;
             out.status = r.status;
-            out.stage = PQ_STAGE_NONE;
+            out.stage = r.init_failed ? PQ_STAGE_VALUES_INIT : PQ_STAGE_NONE;  // Init failed, not DecodeValues
             out.detail = 0;
             out.n_decoded = r.n_decoded;
             out.not_null = 0;
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(kWG) void delta_wave_kernel(const pq_page_desc *__r
     if (lane == 0) {
         pq_page_result out;
         out.status = r.status;
-        out.stage = PQ_STAGE_NONE;
+        out.stage = r.init_failed ? PQ_STAGE_VALUES_INIT : PQ_STAGE_NONE;
         out.detail = 0;
         out.n_decoded = r.n_decoded;
         out.not_null = 0;
@@ -696,6 +697,7 @@ __global__ __launch_bounds__(kHwWG) void stream_wave_kernel(const pq_page_desc *
             if (flags & PQ_FLAG_LENGTH_PREFIXED) sec = section_init_size(S, len, w);
             if (sec.init_status != PQ_OK) {
                 r.status = sec.init_status;
+                if (brle) stage = PQ_STAGE_VALUES_INIT;  // BooleanRLEDecoder.Init failed, not DecodeValues
             } else if (levels) {
                 r = run_section_wave<HY_LEVELS, uint32_t>(L, sec, w, n, dst, nullptr, 0, d.max_def, lane);
                 if (r.status != PQ_OK) { r.n_decoded = 0; r.count_max = 0; }
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(kHwWG) void stream_wave_kernel(const pq_page_desc *
         else
             r = dict_values_wave<uint32_t>(L, S, len, n, reinterpret_cast<uint32_t *>(buf.values + d.dst_off), wd,
                                            d.dict_len, &init_status, lane);
-        (void)init_status;
+        if (init_status != PQ_OK) stage = PQ_STAGE_VALUES_INIT;  // DictDecoder.Init failed
     }
     if (lane == 0) {
         pq_page_result out;
@@ -936,7 +938,7 @@ __global__ __launch_bounds__(kWave) void delta_serial_kernel(const pq_page_desc 
         r = delta_serial<uint32_t>(S, len, n, reinterpret_cast<uint32_t *>(buf.values + d.dst_off));
     if (!is_page) {
         out.status = r.status;
-        out.stage = PQ_STAGE_NONE;
+        out.stage = r.init_failed ? PQ_STAGE_VALUES_INIT : PQ_STAGE_NONE;
         out.detail = 0;
         out.n_decoded = r.n_decoded;
         out.not_null = 0;
@@ -956,6 +958,60 @@ __global__ __launch_bounds__(kWave) void delta_serial_kernel(const pq_page_desc 
                     not_null, n, size);
     }
     results[page] = out;
+}
+
+// Data pages of flat columns (max_rep == 0, max_def == 0) that the host turned into the value streams
+// they are: results[page] holds what the stream kernels left (status, count, stage == VALUES_INIT
+// when the decoder's Init failed); ReadValues' outcome is made of it here (layout/page-v1.go:80-116:
+// both level arrays are n constant zeros, every slot is a value).
+__global__ __launch_bounds__(kWave) void lowered_finish_kernel(const pq_page_desc *__restrict__ descs,
+                                                               const uint32_t *__restrict__ ids, uint32_t count,
+                                                               pq_page_result *__restrict__ results)
+{
+    const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t page = ids[i];
+    const pq_page_result r = results[page];
+    const uint32_t n = descs[page].n_values;
+    pq_page_result out;
+    out.status = PQ_OK;
+    out.stage = PQ_STAGE_NONE;
+    out.detail = 0;
+    out.n_decoded = 0;
+    out.not_null = 0;
+    out.n_levels = 0;
+    out.consumed = 0;
+    finish_page(out, r.stage == PQ_STAGE_VALUES_INIT ? r.status : PQ_OK, r.status, r.n_decoded, PQ_OK, PQ_STAGE_NONE, n, n,
+                n);
+    results[page] = out;
+}
+
+// Their constant levels, for the callers that want them written: blockIdx.x = page, the slots dealt
+// out over blockIdx.y.
+__global__ __launch_bounds__(kWG) void lowered_levels_kernel(const pq_page_desc *__restrict__ descs,
+                                                             const uint32_t *__restrict__ ids, PageBuffers buf)
+{
+    const pq_page_desc &d = descs[ids[blockIdx.x]];
+    if (d.flags & PQ_FLAG_NO_LEVEL_OUTPUT) return;
+    uint32_t *rep = reinterpret_cast<uint32_t *>(buf.levels + d.rep_off);
+    uint32_t *def = reinterpret_cast<uint32_t *>(buf.levels + d.def_off);
+    const uint32_t n = d.n_values;
+    for (uint32_t i = blockIdx.y * kWG + threadIdx.x; i < n; i += gridDim.y * kWG) {
+        rep[i] = 0;
+        def[i] = 0;
+    }
+}
+
+hipError_t launch_lowered_finish(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids, uint32_t count,
+                                 PageBuffers buf, pq_page_result *d_results, bool write_levels)
+{
+    if (count == 0) return hipSuccess;
+    if (write_levels)
+        hipLaunchKernelGGL(lowered_levels_kernel, dim3(count, count >= 1024u ? 4u : 64u), dim3(kWG), 0, s, d_descs, d_ids,
+                           buf);
+    hipLaunchKernelGGL(lowered_finish_kernel, dim3((count + kWave - 1) / kWave), dim3(kWave), 0, s, d_descs, d_ids, count,
+                       d_results);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------

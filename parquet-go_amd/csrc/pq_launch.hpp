@@ -58,6 +58,12 @@ hipError_t launch_byte_arrays(hipStream_t s, uint32_t kind, const pq_page_desc *
 hipError_t launch_delta_serial(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
                                uint32_t count, PageBuffers buf, pq_page_result *d_results);
 
+// Behind every other kernel of a run: ids[0..count) name descriptors that were data pages of a flat
+// column and ran as their value streams; turns each stream result into the page's, and writes the
+// pages' constant levels where asked for (write_levels: some descriptor lacks PQ_FLAG_NO_LEVEL_OUTPUT).
+hipError_t launch_lowered_finish(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids, uint32_t count,
+                                 PageBuffers buf, pq_page_result *d_results, bool write_levels);
+
 constexpr uint32_t kDictLdsMax = 48u * 1024u;
 
 // ---- segmented delta pages (segdelta.hip) -------------------------------------------------------

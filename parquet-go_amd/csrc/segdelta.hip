@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kWG) void seg_decode_kernel(const pq_page_desc *__r
     if (lane == 0) {
         pq_page_result out;
         out.status = r.status;
-        out.stage = PQ_STAGE_NONE;
+        out.stage = r.init_failed ? PQ_STAGE_VALUES_INIT : PQ_STAGE_NONE;  // Init failed, not DecodeValues
         out.detail = 0;
         out.n_decoded = r.n_decoded;
         out.not_null = 0;

@@ -210,14 +210,17 @@ __global__ __launch_bounds__(kHsWG) void hseg_decode_kernel(const pq_page_desc *
     HybridResult r{PQ_OK, 0, 0, 0};
     if (flags == kSegWhole) {
         // the whole stream as stream_wave_kernel decodes it
+        int32_t stage = PQ_STAGE_NONE;
         if (d.kind == PQ_KIND_DICT) {
             if (len <= 0) {
                 r.status = PQ_EOF;
+                stage = PQ_STAGE_VALUES_INIT;  // DictDecoder.Init failed
             } else {
                 const uint32_t w = uni((uint32_t)S[0]);
                 if (w > 32u) {
                     r.status = PQ_DICT_INVALID_WIDTH;
                     r.consumed = 1;
+                    stage = PQ_STAGE_VALUES_INIT;
                 } else {
                     r = es == 8u ? hseg_values<uint64_t>(L, d.kind, S + 1, len - 1, w, d.n_values, dst, gdict, ldict, d.dict_len, lane)
                                  : hseg_values<uint32_t>(L, d.kind, S + 1, len - 1, w, d.n_values, dst, gdict, ldict, d.dict_len, lane);
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(kHsWG) void hseg_decode_kernel(const pq_page_desc *
         if (lane == 0) {
             pq_page_result out;
             out.status = r.status;
-            out.stage = PQ_STAGE_NONE;
+            out.stage = stage;
             out.detail = 0;
             out.n_decoded = r.n_decoded;
             out.not_null = 0;
