@@ -1,6 +1,8 @@
 """The allocation-free entry point (pq_column_entries_noalloc: static device workspace inside the
 library) against pq_column_entries_dev on the same device buffers: bit-exact outputs on two calls
-in a row, the second over a smaller input, plus the size limit."""
+in a row, the second over a smaller input, plus the size limit; that it allocates no device memory;
+and that calls from two contexts on two streams, back to back with no wait between them, are put in
+order by the library (they share the one workspace of the GPU)."""
 import numpy as np
 import pytest
 
@@ -75,3 +77,71 @@ def test_noalloc_against_oracle():
             assert val.numpy().view(np.uint8)[: (n + 31) // 32 * 4].tobytes() == want["validity"].tobytes()
     finally:
         ctx.close()
+
+
+def test_noalloc_allocates_nothing():
+    """A fresh context has no workspace of its own yet: the first call through the allocation-free entry point, over a
+    large input, must leave the device's free memory where it was (the allocating entry point does not)."""
+    import torch
+    from parquet_go_amd import capi
+    dev = torch.device("cuda:0")
+    n = 20_000_000
+    deff, rep = _levels(n, 11, dev)
+    offsets = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    validity = torch.empty((n + 31) // 32 + 1, dtype=torch.int32, device=dev)
+    edef = torch.empty(n, dtype=torch.int32, device=dev)
+    res = torch.zeros(4, dtype=torch.int32, device=dev)
+    ctx = capi.Context(0)
+    try:
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        ctx.column_entries_dev(deff.data_ptr(), rep.data_ptr(), n, 3, 1, True, offsets.data_ptr(), validity.data_ptr(),
+                               edef.data_ptr(), res.data_ptr(), noalloc=True)
+        ctx.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free_before
+        assert res.cpu().tolist()[0] == 0
+        ne = int(res[1])
+        # and the other entry point, on the same context, does take memory (the check above can tell)
+        ctx.column_entries_dev(deff.data_ptr(), rep.data_ptr(), n, 3, 1, True, offsets.data_ptr(), validity.data_ptr(),
+                               edef.data_ptr(), res.data_ptr(), noalloc=False)
+        ctx.synchronize()
+        assert torch.cuda.mem_get_info()[0] < free_before
+        assert int(res[1]) == ne
+    finally:
+        ctx.close()
+
+
+def test_noalloc_calls_of_two_contexts_are_put_in_order():
+    """Two contexts, each with a stream of its own, call back to back without waiting: the second call clears the
+    records the first one's workgroups wait on, so the library has to hold it back until the first is done."""
+    import torch
+    from parquet_go_amd import capi
+    dev = torch.device("cuda:0")
+    a, b = capi.Context(0), capi.Context(0)
+    try:
+        n1, n2 = 8_000_003, 1_000_001
+        d1, r1 = _levels(n1, 21, dev)
+        d2, r2 = _levels(n2, 22, dev)
+        want1 = _run(a, d1, r1, n1, True, noalloc=False)
+        want2 = _run(b, d2, r2, n2, True, noalloc=False)
+        outs = []
+        for n in (n1, n2):
+            outs.append((torch.full((n + 1,), -1, dtype=torch.int32, device=dev),
+                         torch.full(((n + 31) // 32 + 1,), -1, dtype=torch.int32, device=dev),
+                         torch.full((n,), -1, dtype=torch.int32, device=dev),
+                         torch.full((4,), -1, dtype=torch.int32, device=dev)))
+        torch.cuda.synchronize()
+        for rounds in range(3):
+            for ctx, (d, r, n), o in ((a, (d1, r1, n1), outs[0]), (b, (d2, r2, n2), outs[1])):
+                ctx.column_entries_dev(d.data_ptr(), r.data_ptr(), n, 3, 1, True, o[0].data_ptr(), o[1].data_ptr(),
+                                       o[2].data_ptr(), o[3].data_ptr(), noalloc=True)
+        a.synchronize()
+        b.synchronize()
+        for want, o, n in ((want1, outs[0], n1), (want2, outs[1], n2)):
+            status, ne, nv, _ = o[3].cpu().tolist()
+            assert (status, ne, nv) == (0, want[0], want[1])
+            assert torch.equal(o[0][: ne + 1].cpu(), want[2]) and torch.equal(o[1][: (n + 31) // 32].cpu(), want[3])
+            assert torch.equal(o[2][:ne].cpu(), want[4])
+    finally:
+        a.close()
+        b.close()

@@ -172,7 +172,9 @@ def bench_nested(ctx, stream, pages, n, distinct=100):
     plan.close()
 
 
-def bench_delta(ctx, stream, pages, n, bits, width, label=""):
+def bench_delta(ctx, stream, pages, n, bits, width, label="", as_pages=False):
+    """as_pages: the same streams as PQ_KIND_PAGE_V1 descriptors of a flat REQUIRED column (what
+    pq_chunks_page_descs makes of a walked chunk) instead of bare PQ_KIND_DELTA32/64."""
     rng = np.random.default_rng(3)
     dt = np.int64 if bits == 64 else np.int32
     streams, keep = [], {}
@@ -185,6 +187,9 @@ def bench_delta(ctx, stream, pages, n, bits, width, label=""):
     src, offs, lens = pack_pages(streams)
     descs = np.zeros(pages, dtype=capi.DESC_DTYPE)
     descs["kind"] = capi.KIND_DELTA64 if bits == 64 else capi.KIND_DELTA32
+    if as_pages:
+        descs["value_kind"] = descs["kind"]
+        descs["kind"], descs["flags"] = capi.KIND_PAGE_V1, capi.FLAG_NO_LEVEL_OUTPUT
     descs["src_off"], descs["src_len"], descs["n_values"] = offs, lens, n
     es = bits // 8
     descs["dst_off"] = np.arange(pages, dtype=np.uint64) * np.uint64(es * n)
@@ -410,6 +415,10 @@ def main():
             bench_delta(ctx, stream, 1000, 100_000, 64, 16, lab)
             bench_delta(ctx, stream, 100, 1_000_000, 32, 12, lab)
         ctx.set_option(capi.OPT_SEGMENT_MAX_PAGES, 1024)
+    if args.only and want("c2pages"):   # a parquet-mr style row group: 16 columns x 8 pages x 131 072 int64
+        bench_delta(ctx, stream, 128, 131072, 64, 16, ", bare DELTA64 descriptors")
+        bench_delta(ctx, stream, 128, 131072, 64, 16, ", PAGE_V1 descriptors of a flat column", as_pages=True)
+        bench_delta(ctx, stream, 128, 131072, 32, 12, ", PAGE_V1 descriptors of a flat column", as_pages=True)
     if want("plain"):
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_PLAIN, 8, "P PLAIN int64")
         bench_plain(ctx, stream, args.pages, 20000, capi.KIND_PLAIN, 4, "P PLAIN int32")
