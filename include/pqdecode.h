@@ -109,6 +109,12 @@ int pq_ctx_synchronize(pq_ctx *ctx);
  * its large ones decoded in segments, many waves to a page (a page is one serial chain of blocks,
  * encoding/delta-binary-packed-decoder.go:130-147; a few large pages would otherwise leave most of
  * the machine idle; measured on MI355X the cut pays below about 1000 pages, whatever their size).
+ * Only blocks whose minDelta varint has at most 4 bytes and whose miniblock widths are at most 32
+ * can be skipped over without decoding them: a page is cut up to its first block that is wider (an
+ * INT64 column with deltas of 2^32 and more is rejected by the reference anyway,
+ * encoding/delta-binary-packed-decoder.go:78-88; one whose minDelta exceeds 2^27 in size is decoded
+ * from that block on by one wave).  Data pages of flat columns (PQ_KIND_PAGE_V1/_V2 with
+ * max_rep == 0, max_def == 0) are cut like the bare streams of their value encoding.
  * Dictionary-index pages (PQ_KIND_DICT) and raw hybrid streams (PQ_KIND_HYBRID without flags)
  * whose runs are bit-packed runs of one repeated length (encoding/hybrid-decoder.go:111-136) are cut
  * the same way under the same option.  Default 1024; 0 = never.  Results are the same either way.
@@ -221,7 +227,10 @@ typedef struct pq_page_desc {
 
 typedef struct pq_page_result {
     int32_t status;      /* PQ_OK or the reference's error class */
-    int32_t stage;       /* PQ_STAGE_*: pages only */
+    int32_t stage;       /* PQ_STAGE_*: pages.  Bare DICT, DELTA32/64, BOOL_RLE and byte-array
+                            descriptors: PQ_STAGE_VALUES_INIT when the error is the decoder's Init's
+                            (types/dict.go:66-89, types/int32.go:103-106, types/boolean.go:177-181),
+                            PQ_STAGE_NONE when it is DecodeValues' */
     int32_t detail;      /* underlying status when status == PQ_PAGE_VALUES_FAILED */
     uint32_t n_decoded;  /* values written (what DecodeValues returns); levels: slots */
     uint32_t not_null;   /* LEVELS and pages: #{def == max_def} */
@@ -252,6 +261,30 @@ int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_valu
                 size_t dict_bytes);
 /* Waits for the stream and copies the per-page results to host memory. */
 int pq_plan_results(pq_plan *plan, pq_page_result *results);
+
+/* One plan over the pages of MANY column chunks that lie in buffers of their own: the loop over a
+ * row group's columns (readRowGroup, file-reader.go:156-191; one readPageData per chunk,
+ * file-reader.go:268-302) as a single set of launches, so that chunks of a few hundred pages each
+ * fill the machine together instead of one after the other.  A buffer set is what pq_plan_run takes
+ * for one chunk; descriptors first_desc[k] .. first_desc[k + 1] - 1 belong to set k and their
+ * offsets are relative to that set's buffers (first_desc: n_sets + 1 ascending entries from 0 to
+ * n_pages — the table pq_chunks_page_descs fills).  pq_plan_run_sets takes the sets in the same
+ * order, checks each against what its descriptors reach, and launches once; results are in
+ * descriptor order as for any plan.  pq_plan_run refuses such a plan and pq_plan_run_sets one made
+ * by pq_plan_create with n_sets != 1 (PQ_ERR_BAD_ARGUMENT). */
+typedef struct pq_buffer_set {
+    const void *d_src;
+    size_t src_bytes;
+    void *d_values;
+    size_t values_bytes;
+    void *d_levels;
+    size_t levels_bytes;
+    const void *d_dict;
+    size_t dict_bytes;
+} pq_buffer_set;
+int pq_plan_create_sets(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, const uint32_t *first_desc,
+                        size_t n_sets, pq_plan **out);
+int pq_plan_run_sets(pq_plan *plan, const pq_buffer_set *sets, size_t n_sets);
 /* Diagnostics (no counterpart in the reference): how the last pq_plan_run treated the delta pages
  * it cut into segments (PQ_OPT_SEGMENT_MAX_PAGES).  One record per segment, pages in plan order,
  * a page's segments in stream order; *n_segments = how many there are, at most `cap` are copied
@@ -506,8 +539,13 @@ int pq_column_entries_dev(pq_ctx *ctx, const int32_t *d_def, const int32_t *d_re
  * arguments, same outputs; the workspace is a static device array inside the library (8 MiB on
  * every GPU the library runs on, held until the process ends), so the call allocates nothing and
  * frees nothing.  n <= PQ_NOALLOC_MAX_SLOTS, else PQ_ERR_OUT_OF_RANGE.  All calls on one GPU share
- * that array, whatever their context: calls that overlap on one GPU race; run them in stream
- * order or one after the other. */
+ * that array, whatever their context or stream, so the library puts them in order: a call's
+ * kernels start when those of the call before it on that GPU are done (an event wait on the
+ * caller's stream; a call never blocks the host).  A stream that is being captured into a HIP
+ * graph is exempt (events recorded outside a capture cannot be waited for inside it): the recorded
+ * launches are ordered by the graph, and a replay must not overlap another call on the same GPU —
+ * overlapping calls do not merely race, the earlier one's workgroups can wait for ever on records
+ * the later one cleared.  The launches hold no memset nodes, only kernels. */
 #define PQ_NOALLOC_MAX_SLOTS 30000000ull
 int pq_column_entries_noalloc(pq_ctx *ctx, const int32_t *d_def, const int32_t *d_rep, uint64_t n,
                               uint32_t max_def, uint32_t max_rep, int repeated, uint32_t *d_offsets,

@@ -37,6 +37,7 @@ EXPORTS = [
     "pq_last_error",
     "pq_version", "pq_bitunpack32_dev", "pq_bitunpack64_dev", "pq_bitunpack32", "pq_bitunpack64",
     "pq_plan_create", "pq_plan_run", "pq_plan_results", "pq_plan_segments", "pq_plan_destroy", "pq_decode_pages",
+    "pq_plan_create_sets", "pq_plan_run_sets",
     "pq_decode_chunks", "pq_host_alloc", "pq_host_free",
     "pq_hybrid_decode", "pq_dict_decode", "pq_levels_decode", "pq_delta_decode32",
     "pq_delta_decode64", "pq_plain_decode", "pq_bool_plain_decode",
@@ -69,6 +70,11 @@ class ChunkJob(C.Structure):
 
 
 CHUNKS_PINNED = 1
+
+
+class BufferSet(C.Structure):
+    _fields_ = [("d_src", C.c_void_p), ("src_bytes", C.c_size_t), ("d_values", C.c_void_p), ("values_bytes", C.c_size_t),
+                ("d_levels", C.c_void_p), ("levels_bytes", C.c_size_t), ("d_dict", C.c_void_p), ("dict_bytes", C.c_size_t)]
 
 
 class EntriesResult(C.Structure):
@@ -139,6 +145,9 @@ def load():
         lib.pq_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         lib.pq_plan_results.argtypes = [C.c_void_p, C.c_void_p]
+        lib.pq_plan_create_sets.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.POINTER(C.c_void_p)]
+        lib.pq_plan_run_sets.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.pq_decode_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]
         lib.pq_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
         lib.pq_host_alloc.restype = C.c_void_p
@@ -456,8 +465,10 @@ class Context:
             raise PqError(st, "(pq_walk_chunks_dev) " + self._lib.pq_last_error(self._h).decode())
         return res[:ch.size]
 
-    def plan(self, descs):
-        p = Plan(self, descs)
+    def plan(self, descs, first_desc=None):
+        """first_desc: None for a plan over one set of buffers (run()); else n_sets + 1 descriptor indices, set k
+        owning descs[first_desc[k]:first_desc[k + 1]] (run_sets())."""
+        p = Plan(self, descs, first_desc)
         self._plans.add(p)
         return p
 
@@ -481,16 +492,33 @@ def chunk_page_descs(chunk, infos, layout):
 class Plan:
     """A pq_plan: uploaded descriptor table; run() only launches kernels."""
 
-    def __init__(self, ctx, descs):
+    def __init__(self, ctx, descs, first_desc=None):
         self._ctx = ctx
         self._lib = ctx._lib
         descs = np.ascontiguousarray(descs, dtype=DESC_DTYPE)
         self.n = descs.size
         h = C.c_void_p()
-        st = self._lib.pq_plan_create(ctx._h, _ptr(descs), descs.size, C.byref(h))
+        if first_desc is None:
+            st = self._lib.pq_plan_create(ctx._h, _ptr(descs), descs.size, C.byref(h))
+        else:
+            first = np.ascontiguousarray(first_desc, dtype=np.uint32)
+            self.n_sets = first.size - 1
+            st = self._lib.pq_plan_create_sets(ctx._h, _ptr(descs), descs.size, first.ctypes.data, self.n_sets, C.byref(h))
         if st != OK:
             raise PqError(st, "(pq_plan_create) " + self._lib.pq_last_error(ctx._h).decode())
         self._h = h
+
+    def run_sets(self, sets):
+        """sets: one (d_src, src_bytes, d_values, values_bytes, d_levels, levels_bytes, d_dict, dict_bytes) per
+        buffer set, device pointers as integers (0 = none)."""
+        arr = (BufferSet * max(len(sets), 1))()
+        for a, t in zip(arr, sets):
+            t = tuple(t) + (0,) * (8 - len(t))
+            (a.d_src, a.src_bytes, a.d_values, a.values_bytes, a.d_levels, a.levels_bytes, a.d_dict, a.dict_bytes) = (
+                t[0] or None, int(t[1]), t[2] or None, int(t[3]), t[4] or None, int(t[5]), t[6] or None, int(t[7]))
+        st = self._lib.pq_plan_run_sets(self._h, arr, len(sets))
+        if st != OK:
+            raise PqError(st, "(pq_plan_run_sets) " + self._lib.pq_last_error(self._ctx._h).decode())
 
     def run(self, d_src, src_bytes, d_values=0, values_bytes=0, d_levels=0, levels_bytes=0,
             d_dict=0, dict_bytes=0):

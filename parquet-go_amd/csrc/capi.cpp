@@ -69,6 +69,10 @@ struct ChunkSlot {
 
 constexpr int kGroups = 6;  // kernel groups of a plan
 
+struct SetNeed {
+    uint64_t src = 0, values = 0, levels = 0, dict = 0;
+};
+
 struct pq_plan {
     pq_ctx *ctx = nullptr;
     size_t n = 0;
@@ -82,11 +86,7 @@ struct pq_plan {
     // [stream | delta32 | delta64 | data pages | DELTA_LENGTH_BYTE_ARRAY | DELTA_BYTE_ARRAY]
     uint32_t count[kGroups] = {0, 0, 0, 0, 0, 0};
     uint32_t first[kGroups] = {0, 0, 0, 0, 0, 0};
-    uint64_t src_need = 0, values_need = 0, levels_need = 0, dict_need = 0;
-    uint32_t dict_lds_bytes = 0;
-    // set when every dictionary user reads one and the same dictionary that fits LDS
-    uint32_t shared_dict_bytes = 0;
-    uint64_t shared_dict_off = 0;
+    uint32_t dict_lds_bytes = 0;  // the largest dictionary that fits LDS: what a workgroup sets aside for its copy
     bool has_delta_page = false; // some PAGE_V1/V2 descriptor carries delta values
     // delta32 / delta64 descriptors that are decoded in segments: the last n_seg_pages[k] ids of
     // group 1 + k, their page records, the segment -> page map and the segment records
@@ -105,6 +105,17 @@ struct pq_plan {
     uint32_t n_lowered = 0;
     uint32_t *d_lowered = nullptr;
     bool lowered_levels = false;
+    // Plans over several buffer sets (pq_plan_create_sets): descriptor i belongs to set set_of[i]; its
+    // offsets are relative to that set's buffers.  d_descs0 keeps the table as created; every run
+    // writes d_descs from it with the offsets moved to the first set's buffers (d_deltas: per set,
+    // how far its src / values / levels / dict buffers lie behind the first set's).
+    size_t n_sets = 1;
+    std::vector<SetNeed> need;         // per set: bytes of each buffer the descriptors reach
+    pq_page_desc *d_descs0 = nullptr;
+    uint32_t *d_set_of = nullptr;
+    uint64_t *d_deltas = nullptr;
+    uint64_t *h_deltas = nullptr;      // pinned, 4 words per set
+    hipEvent_t deltas_sent = nullptr;  // recorded behind the copy out of h_deltas
 };
 
 namespace {
@@ -481,22 +492,32 @@ int pq_bitunpack64(pq_ctx *ctx, const uint8_t *src, size_t src_len, int w, size_
 
 // ---- plans ------------------------------------------------------------------
 
-int pq_plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pages, pq_plan **out)
+static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pages, const uint32_t *first_desc,
+                       size_t n_sets, pq_plan **out)
 {
-    if (!ctx || !out || (n_pages && !user_descs) || n_pages > 0x7fffffffu) return PQ_ERR_BAD_ARGUMENT;
+    if (!ctx || !out || (n_pages && !user_descs) || n_pages > 0x7fffffffu || n_sets == 0 || n_sets > 0xffffffu)
+        return PQ_ERR_BAD_ARGUMENT;
     *out = nullptr;
+    if (first_desc) {  // set k owns descriptors [first_desc[k], first_desc[k + 1])
+        if (first_desc[0] != 0 || first_desc[n_sets] != n_pages) return PQ_ERR_BAD_ARGUMENT;
+        for (size_t k = 0; k < n_sets; ++k)
+            if (first_desc[k] > first_desc[k + 1]) return PQ_ERR_BAD_ARGUMENT;
+    } else if (n_sets != 1) {
+        return PQ_ERR_BAD_ARGUMENT;
+    }
     std::vector<uint32_t> ids[kGroups];
     pq_plan *plan = new (std::nothrow) pq_plan;
     if (!plan) return PQ_ERR_BAD_ARGUMENT;
     plan->ctx = ctx;
     plan->n = n_pages;
+    plan->n_sets = n_sets;
+    plan->need.resize(n_sets);
     uint64_t dict_bytes_max = 0;
-    bool dict_seen = false, dict_shared = true;
-    uint64_t dict0_off = 0, dict0_bytes = 0;
     // the table the kernels see: the caller's, with the pages of flat columns turned into the value
     // streams they are
     std::vector<pq_page_desc> descs(user_descs, user_descs + n_pages);
-    std::vector<uint32_t> lowered;
+    std::vector<uint32_t> lowered, set_of(n_sets > 1 ? n_pages : 0);
+    size_t set = 0;
     for (size_t i = 0; i < n_pages; ++i) {
         const pq_page_desc &d = user_descs[i];
         const int st = validate(d);
@@ -504,32 +525,27 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pages, 
             delete plan;
             return st;
         }
-        plan->src_need = std::max(plan->src_need, d.src_off + d.src_len);
+        while (first_desc && i >= first_desc[set + 1]) ++set;
+        if (n_sets > 1) set_of[i] = (uint32_t)set;
+        SetNeed &need = plan->need[set];
+        need.src = std::max(need.src, d.src_off + d.src_len);
         const uint32_t vs = value_size(d);
-        if (vs) plan->values_need = std::max(plan->values_need, d.dst_off + (uint64_t)d.n_values * vs);
+        if (vs) need.values = std::max(need.values, d.dst_off + (uint64_t)d.n_values * vs);
         const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
         if (const uint32_t ba = byte_array_kind(d)) {
             const bool front = ba == PQ_KIND_DELTA_BA;  // values rebuilt from prefixes: caller-sized
-            plan->values_need = std::max(plan->values_need, d.dst_off + (front ? (uint64_t)d.dst_cap : d.src_len));
-            plan->values_need = std::max(plan->values_need,
-                                         d.dict_off + (uint64_t)4 * ((uint64_t)(front ? 2 : 1) * d.dict_len + 1));
+            need.values = std::max(need.values, d.dst_off + (front ? (uint64_t)d.dst_cap : d.src_len));
+            need.values = std::max(need.values, d.dict_off + (uint64_t)4 * ((uint64_t)(front ? 2 : 1) * d.dict_len + 1));
         }
         // a page of a flat column that keeps its constant-zero levels to itself needs no level room
         const bool no_levels = page && d.max_rep == 0 && (d.flags & PQ_FLAG_NO_LEVEL_OUTPUT) != 0;
         if ((page && !no_levels) || d.kind == PQ_KIND_LEVELS)
-            plan->levels_need = std::max(plan->levels_need, d.def_off + (uint64_t)4 * d.n_values);
-        if (page && !no_levels) plan->levels_need = std::max(plan->levels_need, d.rep_off + (uint64_t)4 * d.n_values);
+            need.levels = std::max(need.levels, d.def_off + (uint64_t)4 * d.n_values);
+        if (page && !no_levels) need.levels = std::max(need.levels, d.rep_off + (uint64_t)4 * d.n_values);
         if (d.kind == PQ_KIND_DICT || (page && d.value_kind == PQ_KIND_DICT)) {
             const uint64_t db = (uint64_t)d.dict_len * d.elem_size;
-            plan->dict_need = std::max(plan->dict_need, d.dict_off + db);
+            need.dict = std::max(need.dict, d.dict_off + db);
             if (db <= pq::kDictLdsMax) dict_bytes_max = std::max(dict_bytes_max, db);
-            if (!dict_seen) {
-                dict_seen = true;
-                dict0_off = d.dict_off;
-                dict0_bytes = db;
-            } else if (d.dict_off != dict0_off || db != dict0_bytes) {
-                dict_shared = false;
-            }
         }
         if (lower_flat_page(descs[i])) {
             lowered.push_back((uint32_t)i);
@@ -543,10 +559,6 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pages, 
     }
     plan->n_lowered = (uint32_t)lowered.size();
     plan->dict_lds_bytes = (uint32_t)((dict_bytes_max + 15u) & ~15ull);
-    if (dict_seen && dict_shared && dict0_bytes != 0 && dict0_bytes <= pq::kDictLdsMax) {
-        plan->shared_dict_bytes = (uint32_t)dict0_bytes;
-        plan->shared_dict_off = dict0_off;
-    }
 
     if (hipSetDevice(ctx->device) != hipSuccess) {
         delete plan;
@@ -674,7 +686,11 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pages, 
         const Region r_hs = take(hseg_seg_owner.size() * sizeof(uint32_t));
         const Region r_hc = take(hseg_check_owner.size() * sizeof(uint32_t));
         const Region r_low = take(lowered.size() * sizeof(uint32_t));
+        const Region r_set = take(set_of.size() * sizeof(uint32_t));
+        // several buffer sets: the table as created stays here, every run derives r_descs from it
+        const Region r_descs0 = take(n_sets > 1 ? n_pages * sizeof(pq_page_desc) : 0);
         const size_t img_bytes = img;
+        const Region r_deltas = take(n_sets > 1 ? n_sets * 4 * sizeof(uint64_t) : 0);
         const Region r_res = take(n_pages * sizeof(pq_page_result));
         Region r_sr[2];
         for (int k = 0; k < 2; ++k) r_sr[k] = take(seg_owner[k].size() * sizeof(pq::SegRec));
@@ -734,6 +750,13 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pages, 
             put(r_hs, hseg_seg_owner.data());
             put(r_hc, hseg_check_owner.data());
             put(r_low, lowered.data());
+            if (n_sets > 1) {
+                plan->d_set_of = reinterpret_cast<uint32_t *>(block + r_set.at);
+                plan->d_descs0 = reinterpret_cast<pq_page_desc *>(block + r_descs0.at);
+                plan->d_deltas = reinterpret_cast<uint64_t *>(block + r_deltas.at);
+                put(r_set, set_of.data());
+                put(r_descs0, descs.data());
+            }
             e = hipMemcpyAsync(block, h, img_bytes, hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess) e = hipEventRecord(ctx->host_img_done[slot], ctx->stream);
         } else if (block) {
@@ -741,6 +764,10 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pages, 
         }
         // nothing waits here: the tables are on their way on the stream the plan runs on
         if (e == hipSuccess) e = hipMemsetAsync(plan->d_results, 0xff, n_pages * sizeof(pq_page_result), ctx->stream);
+        if (e == hipSuccess && n_sets > 1) {
+            e = hipHostMalloc((void **)&plan->h_deltas, n_sets * 4 * sizeof(uint64_t), hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&plan->deltas_sent, hipEventDisableTiming);
+        }
         if (e != hipSuccess) {
             hip_ok(ctx, e, "pq_plan_create");
             pq_plan_destroy(plan);
@@ -752,9 +779,25 @@ int pq_plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pages, 
     return PQ_OK;
 }
 
+int pq_plan_create(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, pq_plan **out)
+{
+    return plan_create(ctx, descs, n_pages, nullptr, 1, out);
+}
+
+int pq_plan_create_sets(pq_ctx *ctx, const pq_page_desc *descs, size_t n_pages, const uint32_t *first_desc,
+                        size_t n_sets, pq_plan **out)
+{
+    if (!first_desc) return PQ_ERR_BAD_ARGUMENT;
+    return plan_create(ctx, descs, n_pages, first_desc, n_sets, out);
+}
+
 void pq_plan_destroy(pq_plan *plan)
 {
     if (!plan) return;
+    if (plan->h_deltas) (void)hipHostFree(plan->h_deltas);
+    if (plan->deltas_sent) (void)hipEventDestroy(plan->deltas_sent);
+    plan->h_deltas = nullptr;
+    plan->deltas_sent = nullptr;
     if (!plan->ctx) {  // its context went first and took the device block with it
         delete plan;
         return;
@@ -778,30 +821,15 @@ void pq_plan_destroy(pq_plan *plan)
     delete plan;
 }
 
-int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_values, size_t values_bytes,
-                void *d_levels, size_t levels_bytes, const void *d_dict, size_t dict_bytes)
+// Every kernel of a run, on the context's stream: buf holds the buffers the table's offsets refer to.
+static int plan_launch(pq_plan *plan, pq::PageBuffers buf)
 {
-    if (!plan || !plan->ctx) return PQ_ERR_BAD_ARGUMENT;  // no context: it was destroyed before the plan
     pq_ctx *ctx = plan->ctx;
-    if (plan->n == 0) return PQ_OK;
-    if (plan->src_need > src_bytes || plan->values_need > values_bytes ||
-        plan->levels_need > levels_bytes || plan->dict_need > dict_bytes)
-        return PQ_ERR_OUT_OF_RANGE;
-    if ((plan->src_need && !d_src) || (plan->values_need && !d_values) ||
-        (plan->levels_need && !d_levels) || (plan->dict_need && !d_dict))
-        return PQ_ERR_BAD_ARGUMENT;
-    // value / level outputs are written with naturally aligned element stores
-    if ((reinterpret_cast<uintptr_t>(d_values) & 7u) || (reinterpret_cast<uintptr_t>(d_levels) & 3u) ||
-        (reinterpret_cast<uintptr_t>(d_dict) & 7u))
-        return PQ_ERR_BAD_ARGUMENT;
-    PQ_HIP(ctx, hipSetDevice(ctx->device));
-    pq::PageBuffers buf{(const uint8_t *)d_src, (uint8_t *)d_values, (uint8_t *)d_levels,
-                        (const uint8_t *)d_dict};
-    const pq::WaveLaunch wl{ctx->hybrid_wave_min_pages, plan->shared_dict_bytes, plan->shared_dict_off};
+    const pq::WaveLaunch wl{ctx->hybrid_wave_min_pages};
     PQ_HIP(ctx, pq::launch_seg_hybrid(ctx->stream, plan->d_descs, plan->d_hseg_pages, plan->n_hseg_pages,
                                       plan->d_hseg_check_owner, plan->n_hseg_checks, plan->d_hseg_counts,
                                       plan->d_hseg_seg_owner, plan->n_hseg_segs, plan->d_hseg_recs, buf, plan->d_results,
-                                      plan->shared_dict_bytes, plan->shared_dict_off));
+                                      plan->dict_lds_bytes));
     PQ_HIP(ctx, pq::launch_stream_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[0],
                                         plan->count[0] - plan->n_hseg_pages, buf, plan->d_results, plan->dict_lds_bytes,
                                         wl));
@@ -836,6 +864,71 @@ int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_valu
     PQ_HIP(ctx, pq::launch_lowered_finish(ctx->stream, plan->d_descs, plan->d_lowered, plan->n_lowered, buf,
                                           plan->d_results, plan->lowered_levels));
     return PQ_OK;
+}
+
+// What a run checks of one buffer set before anything is launched.
+static int check_set(const SetNeed &need, const void *d_src, size_t src_bytes, const void *d_values, size_t values_bytes,
+                     const void *d_levels, size_t levels_bytes, const void *d_dict, size_t dict_bytes)
+{
+    if (need.src > src_bytes || need.values > values_bytes || need.levels > levels_bytes || need.dict > dict_bytes)
+        return PQ_ERR_OUT_OF_RANGE;
+    if ((need.src && !d_src) || (need.values && !d_values) || (need.levels && !d_levels) || (need.dict && !d_dict))
+        return PQ_ERR_BAD_ARGUMENT;
+    // value / level outputs are written with naturally aligned element stores
+    if ((reinterpret_cast<uintptr_t>(d_values) & 7u) || (reinterpret_cast<uintptr_t>(d_levels) & 3u) ||
+        (reinterpret_cast<uintptr_t>(d_dict) & 7u))
+        return PQ_ERR_BAD_ARGUMENT;
+    return PQ_OK;
+}
+
+int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_values, size_t values_bytes,
+                void *d_levels, size_t levels_bytes, const void *d_dict, size_t dict_bytes)
+{
+    if (!plan || !plan->ctx || plan->n_sets != 1) return PQ_ERR_BAD_ARGUMENT;  // no context: it was destroyed before the plan
+    pq_ctx *ctx = plan->ctx;
+    if (plan->n == 0) return PQ_OK;
+    const int st = check_set(plan->need[0], d_src, src_bytes, d_values, values_bytes, d_levels, levels_bytes, d_dict,
+                             dict_bytes);
+    if (st != PQ_OK) return st;
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    pq::PageBuffers buf{(const uint8_t *)d_src, (uint8_t *)d_values, (uint8_t *)d_levels,
+                        (const uint8_t *)d_dict};
+    return plan_launch(plan, buf);
+}
+
+int pq_plan_run_sets(pq_plan *plan, const pq_buffer_set *sets, size_t n_sets)
+{
+    if (!plan || !plan->ctx || !sets || n_sets != plan->n_sets) return PQ_ERR_BAD_ARGUMENT;
+    pq_ctx *ctx = plan->ctx;
+    if (plan->n == 0) return PQ_OK;
+    for (size_t k = 0; k < n_sets; ++k) {
+        const pq_buffer_set &b = sets[k];
+        const int st = check_set(plan->need[k], b.d_src, b.src_bytes, b.d_values, b.values_bytes, b.d_levels,
+                                 b.levels_bytes, b.d_dict, b.dict_bytes);
+        if (st != PQ_OK) return st;
+    }
+    PQ_HIP(ctx, hipSetDevice(ctx->device));
+    pq::PageBuffers buf{(const uint8_t *)sets[0].d_src, (uint8_t *)sets[0].d_values, (uint8_t *)sets[0].d_levels,
+                        (const uint8_t *)sets[0].d_dict};
+    if (n_sets == 1) return plan_launch(plan, buf);
+    // Offsets are added to the first set's pointers in 64-bit arithmetic, so a set that lies
+    // anywhere else is reached by moving its descriptors' offsets by the distance between the two
+    // buffers (modulo 2^64).  The run before may still be reading the staging words.
+    PQ_HIP(ctx, hipEventSynchronize(plan->deltas_sent));
+    for (size_t k = 0; k < n_sets; ++k) {
+        const pq_buffer_set &b = sets[k];
+        uint64_t *w = plan->h_deltas + 4 * k;
+        w[0] = (uint64_t)(reinterpret_cast<uintptr_t>(b.d_src) - reinterpret_cast<uintptr_t>(sets[0].d_src));
+        w[1] = (uint64_t)(reinterpret_cast<uintptr_t>(b.d_values) - reinterpret_cast<uintptr_t>(sets[0].d_values));
+        w[2] = (uint64_t)(reinterpret_cast<uintptr_t>(b.d_levels) - reinterpret_cast<uintptr_t>(sets[0].d_levels));
+        w[3] = (uint64_t)(reinterpret_cast<uintptr_t>(b.d_dict) - reinterpret_cast<uintptr_t>(sets[0].d_dict));
+    }
+    PQ_HIP(ctx, hipMemcpyAsync(plan->d_deltas, plan->h_deltas, n_sets * 4 * sizeof(uint64_t), hipMemcpyHostToDevice,
+                               ctx->stream));
+    PQ_HIP(ctx, hipEventRecord(plan->deltas_sent, ctx->stream));
+    PQ_HIP(ctx, pq::launch_rebase(ctx->stream, plan->d_descs0, plan->d_set_of, plan->d_deltas, (uint32_t)plan->n,
+                                  plan->d_descs));
+    return plan_launch(plan, buf);
 }
 
 int pq_plan_results(pq_plan *plan, pq_page_result *results)

@@ -545,8 +545,10 @@ __global__ __launch_bounds__(kWG) void data_pages_kernel(const pq_page_desc *__r
 
 // ---------------------------------------------------------------------------
 // One WAVE per descriptor: kHwWaves descriptors per workgroup, no barrier after the optional
-// dictionary load.  dict_lds_bytes != 0 promises that every dictionary user of the launch
-// reads the same dictionary, dict_lds_bytes long at buf.dict + dict_lds_off.
+// dictionary load.  A workgroup keeps ONE dictionary in LDS: the one its first descriptor reads,
+// when it fits the launch's budget.  Its other waves use that copy when their descriptor names the
+// same dictionary (same offset, same size: the pages of one column chunk, which a plan keeps side
+// by side) and gather from global memory otherwise.
 
 constexpr int kHwWG = 512;               // threads per workgroup of the hybrid wave kernels
 constexpr int kHwWaves = kHwWG / kWave;   // descriptors per workgroup
@@ -556,15 +558,44 @@ struct WaveDict {
     const uint32_t *l; // the workgroup's LDS copy, or nullptr
 };
 
-__device__ __forceinline__ const uint32_t *load_wave_dict(uint8_t *smem_after, PageBuffers buf, uint32_t dict_lds_bytes,
-                                                           uint64_t dict_lds_off)
+// The dictionary a descriptor reads: bytes == 0 when it reads none.
+struct DictRef {
+    uint64_t off;
+    uint32_t bytes;
+};
+
+__device__ __forceinline__ DictRef dict_ref(const pq_page_desc &d)
 {
-    if (dict_lds_bytes == 0) return nullptr;
-    uint32_t *ldict = reinterpret_cast<uint32_t *>(smem_after);
-    const uint32_t *g = reinterpret_cast<const uint32_t *>(buf.dict + dict_lds_off);
-    for (uint32_t i = threadIdx.x; i < dict_lds_bytes / 4u; i += kHwWG) ldict[i] = g[i];
+    const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
+    const bool user = d.kind == PQ_KIND_DICT || (page && d.value_kind == PQ_KIND_DICT);
+    DictRef r{d.dict_off, user ? d.dict_len * d.elem_size : 0u};
+    return r;
+}
+
+// Loads the dictionary of descriptor `first` (the workgroup's first) into LDS when it fits
+// `budget`; every thread of the workgroup calls this with the same arguments.  Returns what is
+// in LDS now (bytes == 0: nothing).
+template <int WG>
+__device__ __forceinline__ DictRef load_wg_dict(uint32_t *ldict, const pq_page_desc &first, PageBuffers buf, uint32_t budget)
+{
+    DictRef r = dict_ref(first);
+    r.off = ((uint64_t)uni((uint32_t)(r.off >> 32)) << 32) | uni((uint32_t)r.off);
+    r.bytes = uni(r.bytes);
+    if (budget == 0u || r.bytes == 0u || r.bytes > budget) {
+        r.bytes = 0u;
+        return r;
+    }
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(buf.dict + r.off);
+    for (uint32_t i = threadIdx.x; i < r.bytes / 4u; i += WG) ldict[i] = g[i];
     __syncthreads();
-    return ldict;
+    return r;
+}
+
+// The LDS copy if it is this descriptor's dictionary, else nullptr.
+__device__ __forceinline__ const uint32_t *wg_dict_for(const uint32_t *ldict, DictRef have, const pq_page_desc &d)
+{
+    const DictRef want = dict_ref(d);
+    return have.bytes != 0u && want.bytes == have.bytes && want.off == have.off ? ldict : nullptr;
 }
 
 template <int MODE, typename OutT>
@@ -666,11 +697,11 @@ __device__ __forceinline__ HybridResult bool_values_wave(HybridWaveLds &L, const
 __global__ __launch_bounds__(kHwWG) void stream_wave_kernel(const pq_page_desc *__restrict__ descs,
                                                           const uint32_t *__restrict__ ids, uint32_t count,
                                                           PageBuffers buf, pq_page_result *__restrict__ results,
-                                                          uint32_t dict_lds_bytes, uint64_t dict_lds_off)
+                                                          uint32_t dict_lds_bytes)
 {
     HybridWaveLds *LW = reinterpret_cast<HybridWaveLds *>(pq_smem);
-    const uint32_t *ldict = load_wave_dict(pq_smem + align16((uint32_t)sizeof(HybridWaveLds) * (kHwWaves)), buf,
-                                           dict_lds_bytes, dict_lds_off);
+    uint32_t *lds_dict = reinterpret_cast<uint32_t *>(pq_smem + align16((uint32_t)sizeof(HybridWaveLds) * (kHwWaves)));
+    const DictRef have = load_wg_dict<kHwWG>(lds_dict, descs[ids[blockIdx.x * kHwWaves]], buf, dict_lds_bytes);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t slot = blockIdx.x * (kHwWaves) + (uint32_t)wave;
@@ -678,6 +709,7 @@ __global__ __launch_bounds__(kHwWG) void stream_wave_kernel(const pq_page_desc *
     HybridWaveLds &L = LW[wave];
     const uint32_t page = ids[slot];
     const pq_page_desc d = descs[page];
+    const uint32_t *ldict = wg_dict_for(lds_dict, have, d);
     const uint8_t *S = buf.src + d.src_off;
     const int64_t len = (int64_t)d.src_len;
     const uint32_t n = d.n_values;
@@ -747,12 +779,11 @@ __global__ __launch_bounds__(kHwWG) void stream_wave_kernel(const pq_page_desc *
 __global__ __launch_bounds__(kHwWG) void data_wave_kernel(const pq_page_desc *__restrict__ descs,
                                                         const uint32_t *__restrict__ ids, uint32_t count,
                                                         PageBuffers buf, pq_page_result *__restrict__ results,
-                                                        uint32_t dict_lds_bytes, uint64_t dict_lds_off,
-                                                        uint32_t *flag, uint32_t epoch)
+                                                        uint32_t dict_lds_bytes, uint32_t *flag, uint32_t epoch)
 {
     HybridWaveLds *LW = reinterpret_cast<HybridWaveLds *>(pq_smem);
-    const uint32_t *ldict = load_wave_dict(pq_smem + align16((uint32_t)sizeof(HybridWaveLds) * (kHwWaves)), buf,
-                                           dict_lds_bytes, dict_lds_off);
+    uint32_t *lds_dict = reinterpret_cast<uint32_t *>(pq_smem + align16((uint32_t)sizeof(HybridWaveLds) * (kHwWaves)));
+    const DictRef have = load_wg_dict<kHwWG>(lds_dict, descs[ids[blockIdx.x * kHwWaves]], buf, dict_lds_bytes);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t slot = blockIdx.x * (kHwWaves) + (uint32_t)wave;
@@ -760,6 +791,7 @@ __global__ __launch_bounds__(kHwWG) void data_wave_kernel(const pq_page_desc *__
     HybridWaveLds &L = LW[wave];
     const uint32_t page = ids[slot];
     const pq_page_desc d = descs[page];
+    const uint32_t *ldict = wg_dict_for(lds_dict, have, d);
     const uint8_t *S = buf.src + d.src_off;
     const int64_t len = (int64_t)d.src_len;
     const uint32_t size = d.n_values;
@@ -1014,6 +1046,37 @@ hipError_t launch_lowered_finish(hipStream_t s, const pq_page_desc *d_descs, con
     return hipGetLastError();
 }
 
+// Plans over several buffer sets: out[i] = in[i] with its offsets moved by how far the buffers of
+// its set lie behind the first set's (deltas: 4 words per set: src, values, levels, dict; 64-bit
+// wrap-around arithmetic), so that every kernel can go on adding offsets to one base pointer.
+__global__ __launch_bounds__(256) void rebase_kernel(const pq_page_desc *__restrict__ in,
+                                                     const uint32_t *__restrict__ set_of,
+                                                     const uint64_t *__restrict__ deltas, uint32_t n,
+                                                     pq_page_desc *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    pq_page_desc d = in[i];
+    const uint64_t *w = deltas + 4u * (size_t)set_of[i];
+    const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
+    const uint32_t vk = page ? d.value_kind : d.kind;
+    d.src_off += w[0];
+    d.dst_off += w[1];
+    d.rep_off += w[2];
+    d.def_off += w[2];
+    // byte arrays keep their offsets area in the values buffer
+    d.dict_off += (vk == PQ_KIND_DELTA_LENGTH_BA || vk == PQ_KIND_DELTA_BA) ? w[1] : w[3];
+    out[i] = d;
+}
+
+hipError_t launch_rebase(hipStream_t s, const pq_page_desc *d_in, const uint32_t *d_set_of, const uint64_t *d_deltas,
+                         uint32_t n, pq_page_desc *d_out)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(rebase_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, d_in, d_set_of, d_deltas, n, d_out);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 
 static size_t wave_lds_bytes(uint32_t dict_lds_bytes)
@@ -1037,10 +1100,10 @@ hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const
     if (count == 0) return hipSuccess;
     if (count >= wl.min_pages) {
         const uint32_t grid = (count + kHwWaves - 1) / kHwWaves;
-        const hipError_t e = allow_lds(stream_wave_kernel, wave_lds_bytes(wl.dict_lds_bytes));
+        const hipError_t e = allow_lds(stream_wave_kernel, wave_lds_bytes(dict_lds_bytes));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(stream_wave_kernel, dim3(grid), dim3(kHwWG), wave_lds_bytes(wl.dict_lds_bytes), s, d_descs,
-                           d_ids, count, buf, d_results, wl.dict_lds_bytes, wl.dict_lds_off);
+        hipLaunchKernelGGL(stream_wave_kernel, dim3(grid), dim3(kHwWG), wave_lds_bytes(dict_lds_bytes), s, d_descs,
+                           d_ids, count, buf, d_results, dict_lds_bytes);
         return hipGetLastError();
     }
     const size_t shmem = align16(sizeof(HybridShared)) + dict_lds_bytes;
@@ -1107,10 +1170,10 @@ hipError_t launch_data_pages(hipStream_t s, const pq_page_desc *d_descs, const u
     const size_t shmem = align16(sizeof(PageShared)) + dict_lds_bytes;
     if (count >= wl.min_pages) {
         const uint32_t grid = (count + kHwWaves - 1) / kHwWaves;
-        const hipError_t ea = allow_lds(data_wave_kernel, wave_lds_bytes(wl.dict_lds_bytes));
+        const hipError_t ea = allow_lds(data_wave_kernel, wave_lds_bytes(dict_lds_bytes));
         if (ea != hipSuccess) return ea;
-        hipLaunchKernelGGL(data_wave_kernel, dim3(grid), dim3(kHwWG), wave_lds_bytes(wl.dict_lds_bytes), s, d_descs,
-                           d_ids, count, buf, d_results, wl.dict_lds_bytes, wl.dict_lds_off, d_flag, epoch);
+        hipLaunchKernelGGL(data_wave_kernel, dim3(grid), dim3(kHwWG), wave_lds_bytes(dict_lds_bytes), s, d_descs,
+                           d_ids, count, buf, d_results, dict_lds_bytes, d_flag, epoch);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(data_pages_kernel<true>, dim3(min(count, 256u)), dim3(kWG), shmem, s, d_descs, d_ids,

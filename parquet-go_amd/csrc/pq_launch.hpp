@@ -22,17 +22,14 @@ struct PageBuffers {
     const uint8_t *dict;
 };
 
-// How the one-wave-per-descriptor kernels are used: from min_pages descriptors on; when every
-// dictionary user of the plan reads the same dictionary (dict_lds_bytes long at dict_lds_off
-// in the dictionary buffer, at most kDictLdsMax) each workgroup keeps a copy of it in LDS.
+// How the one-wave-per-descriptor kernels are used: from min_pages descriptors on.
 struct WaveLaunch {
     uint32_t min_pages;
-    uint32_t dict_lds_bytes;
-    uint64_t dict_lds_off;
 };
 
 // ids: device array of `count` descriptor indices handled by this launch.
-// dict_lds_bytes: LDS set aside for caching a page's dictionary (0 = gather from global).
+// dict_lds_bytes: LDS set aside per workgroup for a copy of a dictionary (0 = gather from global):
+// the largest dictionary of the plan that fits kDictLdsMax.
 hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
                                uint32_t count, PageBuffers buf, pq_page_result *d_results,
                                uint32_t dict_lds_bytes, const WaveLaunch &wl);
@@ -63,6 +60,11 @@ hipError_t launch_delta_serial(hipStream_t s, const pq_page_desc *d_descs, const
 // pages' constant levels where asked for (write_levels: some descriptor lacks PQ_FLAG_NO_LEVEL_OUTPUT).
 hipError_t launch_lowered_finish(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids, uint32_t count,
                                  PageBuffers buf, pq_page_result *d_results, bool write_levels);
+
+// Plans over several buffer sets: d_out[i] = d_in[i] with its offsets moved by d_deltas[4 * d_set_of[i] ..]
+// (src, values, levels, dict).
+hipError_t launch_rebase(hipStream_t s, const pq_page_desc *d_in, const uint32_t *d_set_of, const uint64_t *d_deltas,
+                         uint32_t n, pq_page_desc *d_out);
 
 constexpr uint32_t kDictLdsMax = 48u * 1024u;
 
@@ -139,7 +141,7 @@ struct HsegRec {
 hipError_t launch_seg_hybrid(hipStream_t s, const pq_page_desc *d_descs, HsegPage *d_pages, uint32_t n_pages,
                              const uint32_t *d_check_owner, uint32_t n_checks, uint32_t *d_counts,
                              const uint32_t *d_seg_owner, uint32_t n_segs, HsegRec *d_recs, PageBuffers buf,
-                             pq_page_result *d_results, uint32_t dict_lds_bytes, uint64_t dict_lds_off);
+                             pq_page_result *d_results, uint32_t dict_lds_bytes);
 
 // Level post-processing (assemble.hip).  d_out: ceil(n / 8) * w bytes, 4-byte aligned.
 hipError_t launch_levels_pack(hipStream_t s, const int32_t *d_levels, uint64_t n, int w, uint8_t *d_out);

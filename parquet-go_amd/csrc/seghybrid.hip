@@ -181,16 +181,23 @@ __global__ __launch_bounds__(kHsWG) void hseg_decode_kernel(const pq_page_desc *
                                                             const uint32_t *__restrict__ seg_owner, uint32_t n_segs,
                                                             HsegRec *__restrict__ recs, PageBuffers buf,
                                                             pq_page_result *__restrict__ results,
-                                                            uint32_t dict_lds_bytes, uint64_t dict_lds_off)
+                                                            uint32_t dict_lds_bytes)
 {
     HybridWaveLds *LW = reinterpret_cast<HybridWaveLds *>(pq_hs_smem);
-    const uint32_t *ldict = nullptr;
-    if (dict_lds_bytes != 0u) {  // every dictionary user of the plan reads this one dictionary
-        uint32_t *ld = reinterpret_cast<uint32_t *>(pq_hs_smem + hs_align16((uint32_t)sizeof(HybridWaveLds) * kHsWaves));
-        const uint32_t *gd = reinterpret_cast<const uint32_t *>(buf.dict + dict_lds_off);
-        for (uint32_t i = threadIdx.x; i < dict_lds_bytes / 4u; i += kHsWG) ld[i] = gd[i];
-        __syncthreads();
-        ldict = ld;
+    // the workgroup's LDS copy of a dictionary: the one its first segment's page reads, if it fits
+    uint32_t *ld = reinterpret_cast<uint32_t *>(pq_hs_smem + hs_align16((uint32_t)sizeof(HybridWaveLds) * kHsWaves));
+    uint64_t have_off = 0;
+    uint32_t have_bytes = 0;
+    {
+        const pq_page_desc &d0 = descs[pages[seg_owner[blockIdx.x * kHsWaves]].desc];
+        const uint32_t bytes = uni(d0.kind == PQ_KIND_DICT ? d0.dict_len * d0.elem_size : 0u);
+        if (dict_lds_bytes != 0u && bytes != 0u && bytes <= dict_lds_bytes) {
+            have_off = ((uint64_t)uni((uint32_t)(d0.dict_off >> 32)) << 32) | uni((uint32_t)d0.dict_off);
+            have_bytes = bytes;
+            const uint32_t *gd = reinterpret_cast<const uint32_t *>(buf.dict + have_off);
+            for (uint32_t i = threadIdx.x; i < bytes / 4u; i += kHsWG) ld[i] = gd[i];
+            __syncthreads();
+        }
     }
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -207,6 +214,10 @@ __global__ __launch_bounds__(kHsWG) void hseg_decode_kernel(const pq_page_desc *
     const uint32_t es = d.kind == PQ_KIND_DICT ? d.elem_size : 4u;
     uint8_t *dst = buf.values + d.dst_off;
     const uint8_t *gdict = buf.dict + d.dict_off;
+    const uint32_t *ldict = d.kind == PQ_KIND_DICT && have_bytes != 0u && d.dict_off == have_off &&
+                                    d.dict_len * d.elem_size == have_bytes
+                                ? ld
+                                : nullptr;
     HybridResult r{PQ_OK, 0, 0, 0};
     if (flags == kSegWhole) {
         // the whole stream as stream_wave_kernel decodes it
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(kWG) void hseg_final_kernel(const HsegPage *__restr
 hipError_t launch_seg_hybrid(hipStream_t s, const pq_page_desc *d_descs, HsegPage *d_pages, uint32_t n_pages,
                              const uint32_t *d_check_owner, uint32_t n_checks, uint32_t *d_counts,
                              const uint32_t *d_seg_owner, uint32_t n_segs, HsegRec *d_recs, PageBuffers buf,
-                             pq_page_result *d_results, uint32_t dict_lds_bytes, uint64_t dict_lds_off)
+                             pq_page_result *d_results, uint32_t dict_lds_bytes)
 {
     if (n_pages == 0 || n_segs == 0) return hipSuccess;
     const uint32_t per = kWG / kWave;
@@ -313,7 +324,7 @@ hipError_t launch_seg_hybrid(hipStream_t s, const pq_page_desc *d_descs, HsegPag
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(hseg_decode_kernel, dim3((n_segs + kHsWaves - 1) / kHsWaves), dim3(kHsWG), lds, s, d_descs, d_pages,
-                       d_seg_owner, n_segs, d_recs, buf, d_results, dict_lds_bytes, dict_lds_off);
+                       d_seg_owner, n_segs, d_recs, buf, d_results, dict_lds_bytes);
     hipLaunchKernelGGL(hseg_final_kernel, dim3((n_pages + per - 1) / per), dim3(kWG), 0, s, d_pages, n_pages, d_recs,
                        d_results);
     return hipGetLastError();

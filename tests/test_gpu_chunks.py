@@ -40,16 +40,18 @@ def test_64_chunks_from_host_memory_every_value(ctx):
     assert consumed == sum(i.encoded_bytes for i in wl["infos"])
 
 
-def _small_jobs(rng, n_jobs, alloc):
-    """Chunks of a few pages each: delta64, dictionary, and V1 pages with levels; -> (jobs, checks)"""
+def _small_jobs(rng, n_jobs, alloc, vary_dict=False, max_n=5000):
+    """Chunks of a few pages each: delta64, dictionary, and V1 pages with levels; -> (jobs, checks)
+    vary_dict: every chunk has a dictionary of its own."""
     jobs, checks = [], []
-    d = rng.integers(-2**31, 2**31, size=300, dtype=np.int64).astype(np.int32)
+    d0 = rng.integers(-2**31, 2**31 - 1000, size=300, dtype=np.int64).astype(np.int32)
     for j in range(n_jobs):
+        d = (d0 + j).astype(np.int32) if vary_dict else d0
         kind = j % 3
         streams, want, descs = [], [], []
         n_pages = 1 + j % 5
         for p in range(n_pages):
-            n = int(rng.integers(1, 5000))
+            n = int(rng.integers(1, max_n))
             if n % 128 == 1:
                 n += 1      # the reference's own decoder fails on the last value of such a stream
             if kind == 0:
@@ -169,3 +171,52 @@ def test_a_refused_job_and_failing_pages_do_not_stop_the_others(ctx):
     assert res[0]["status"] == want["status"] != K.OK and res[0]["n_decoded"] == want["n_decoded"]
     got = cut["values"][int(q["dst_off"]): int(q["dst_off"]) + 8 * want["n_decoded"]].view(np.int64)
     assert np.array_equal(got, want["values"])
+
+
+def test_one_plan_over_many_chunks_in_buffers_of_their_own(ctx):
+    """pq_plan_create_sets / pq_plan_run_sets: the chunks of a row group resident in separate device allocations,
+    one plan, one set of launches — same values, levels and results as a plan per chunk, also when the buffers move
+    between two runs of the plan, with a dictionary per chunk, large pages that are cut into segments and an
+    empty set in the middle."""
+    import torch
+    rng = np.random.default_rng(47)
+    dev = torch.device("cuda:0")
+    jobs, checks = _small_jobs(rng, 13, lambda nbytes: np.empty(nbytes, dtype=np.uint8), vary_dict=True, max_n=90000)
+    empty = dict(descs=np.zeros(0, dtype=K.DESC_DTYPE), src=np.zeros(0, np.uint8), values=np.zeros(0, np.uint8))
+    jobs.insert(5, empty)
+    checks.insert(5, [])
+    descs = np.concatenate([j["descs"] for j in jobs])
+    first = np.concatenate([[0], np.cumsum([j["descs"].size for j in jobs])]).astype(np.uint32)
+    plan = ctx.plan(descs, first_desc=first)
+    with pytest.raises(capi.PqError):       # a plan over several sets does not run on one
+        plan.run(0, 0)
+    for attempt in range(2):                # fresh allocations the second time: the buffers have moved
+        pad = torch.empty(int(rng.integers(1, 1 << 20)), dtype=torch.uint8, device=dev)
+        held, sets = [pad], []
+        for j in jobs:
+            t = {}
+            for name in ("src", "values", "levels", "dict"):
+                a = j.get(name)
+                if a is not None and a.size:
+                    src = np.concatenate([a, np.zeros(16, np.uint8)]) if name in ("src", "dict") else np.full(a.size, 0xA5, np.uint8)
+                    t[name] = torch.from_numpy(src).to(dev)
+            held.append(t)
+            g = lambda name, j=j, t=t: (t[name].data_ptr(), j[name].size) if name in t else (0, 0)
+            sets.append(g("src") + g("values") + g("levels") + g("dict"))
+        torch.cuda.synchronize()
+        plan.run_sets(sets)
+        res = plan.results()
+        outcome = []
+        for k, j in enumerate(jobs):
+            for name in ("values", "levels"):
+                if name in held[1 + k]:
+                    j[name] = held[1 + k][name].cpu().numpy()
+            outcome.append((K.OK, res[int(first[k]): int(first[k + 1])]))
+        _check_small(jobs, checks, outcome)
+    with pytest.raises(capi.PqError):       # a set too small for what its descriptors reach
+        short = list(sets)
+        short[0] = (short[0][0], 1) + short[0][2:]
+        plan.run_sets(short)
+    with pytest.raises(capi.PqError):
+        plan.run_sets(sets[:-1])
+    plan.close()

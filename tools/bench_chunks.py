@@ -204,28 +204,51 @@ def main():
         for a in held:
             ctx.host_free(a)
 
-    # ---- the same launches with everything resident ----
+    # ---- the same chunks resident in device memory, every chunk in buffers of its own ----
     stream = torch.cuda.Stream(device=dev)
     rctx = capi.Context(local, stream.cuda_stream)
     t_dict = torch.from_numpy(wl["dictionary"].copy()).to(dev)
-    res_bufs, res_plans = {}, {}
-    for key, (src, _, _, _) in wl["images"].items():
-        res_bufs[key] = (torch.from_numpy(src).to(dev),
-                         torch.empty(wl["pages"] * wl["n"] * ELEM[key[0]], dtype=torch.uint8, device=dev))
-        res_plans[key] = rctx.plan(wl["descs"][key])
+    chunk_bufs, chunk_plans = [], []
+    for c in mine:
+        key = (wl["kinds"][c], c % 4)
+        chunk_bufs.append((torch.from_numpy(wl["images"][key][0]).to(dev),
+                           torch.empty(wl["pages"] * wl["n"] * ELEM[key[0]], dtype=torch.uint8, device=dev)))
+        chunk_plans.append(rctx.plan(wl["descs"][key]))
     torch.cuda.synchronize()
 
+    def set_of(c, bufs):
+        d_src, d_out = bufs
+        dict_args = (t_dict.data_ptr(), 4096 * 4) if wl["kinds"][c] == "dict" else (0, 0)
+        return (d_src.data_ptr(), d_src.numel(), d_out.data_ptr(), d_out.numel(), 0, 0) + dict_args
+
+    def resident_per_chunk():      # one plan per chunk, run one after the other (what pq_decode_chunks launches)
+        for c, bufs, plan in zip(mine, chunk_bufs, chunk_plans):
+            plan.run(*set_of(c, bufs))
+        stream.synchronize()
+    t_res_each = timed(resident_per_chunk)
+
+    # one plan over all of the rank's chunks (pq_plan_create_sets): a single set of launches
+    all_descs = np.concatenate([wl["descs"][(wl["kinds"][c], c % 4)] for c in mine])
+    first = np.arange(len(mine) + 1, dtype=np.uint32) * wl["pages"]
+    big = rctx.plan(all_descs, first_desc=first)
+    sets = [set_of(c, bufs) for c, bufs in zip(mine, chunk_bufs)]
+
     def resident():
-        for c in mine:
-            key = (wl["kinds"][c], c % 4)
-            d_src, d_out = res_bufs[key]
-            if key[0] == "delta":
-                res_plans[key].run(d_src.data_ptr(), d_src.numel(), d_out.data_ptr(), d_out.numel())
-            else:
-                res_plans[key].run(d_src.data_ptr(), d_src.numel(), d_out.data_ptr(), d_out.numel(), 0, 0,
-                                   t_dict.data_ptr(), 4096 * 4)
+        big.run_sets(sets)
         stream.synchronize()
     t_res = timed(resident)
+    res = big.results()
+    assert (res["status"] == 0).all() and (res["n_decoded"] == wl["n"]).all()
+    for j, c in enumerate(mine):       # first, middle and last page of every chunk
+        k = wl["kinds"][c]
+        which = wl["images"][(k, c % 4)][3]
+        got = chunk_bufs[j][1].view(torch.int64 if k == "delta" else torch.int32).view(wl["pages"], wl["n"])
+        for p in (0, wl["pages"] // 2, wl["pages"] - 1):
+            want = wl["pools"][k][which[p]][1]
+            want = want if k == "delta" else wl["dictionary"][want]
+            assert np.array_equal(got[p].cpu().numpy(), want), (c, p)
+    big.close()
+    res_plans = dict(enumerate(chunk_plans))
 
     # ---- the box's plain copy rates (pinned, 1 GiB) ----
     h = torch.empty(1 << 30, dtype=torch.uint8).pin_memory()
@@ -257,6 +280,9 @@ def main():
             "host_to_host_pinned_s": round(times["pinned"], 4),
             "host_to_host_pinned_out_GBps": round(out_bytes / times["pinned"] / 1e9, 2),
             "resident_s": round(t_res, 5), "resident_out_GBps": round(out_bytes / t_res / 1e9, 1),
+            "resident_alg_frac_of_8TBps": round((in_bytes + out_bytes) / t_res / 8e12, 4),
+            "resident_one_plan_per_chunk_s": round(t_res_each, 5),
+            "resident_one_plan_per_chunk_out_GBps": round(out_bytes / t_res_each / 1e9, 1),
             "pinned_copy_GBps": {"h2d": round(h2d, 1), "d2h": round(d2h, 1)},
             "pinned_over_d2h": round(out_bytes / times["pinned"] / 1e9 / d2h, 3),
             "pageable_over_d2h": round(out_bytes / times["pageable"] / 1e9 / d2h, 3),
