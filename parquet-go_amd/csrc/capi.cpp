@@ -100,6 +100,7 @@ struct pq_plan {
     pq::HsegPage *d_hseg_pages = nullptr;
     uint32_t *d_hseg_seg_owner = nullptr, *d_hseg_check_owner = nullptr, *d_hseg_counts = nullptr;
     pq::HsegRec *d_hseg_recs = nullptr;
+    pq::HsegScan *d_hseg_scans = nullptr;  // two records per segment
     // data pages of flat columns that are decoded as the value streams they hold (see lower_flat_page):
     // their ids, and whether any of them wants its constant levels written out
     uint32_t n_lowered = 0;
@@ -630,8 +631,11 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
         }
         auto cut = [&](uint32_t i) {
             const pq_page_desc &d = descs[i];
-            const bool raw = d.kind == PQ_KIND_HYBRID && d.flags == 0u;
-            return (d.kind == PQ_KIND_DICT || raw) && d.src_len >= 3 * L && d.src_len < 0x7fffffffull && d.n_values >= 4096u;
+            // every kind that is a hybrid stream with a reader behind it (hseg_header_kernel looks closer)
+            const bool hybrid = d.kind == PQ_KIND_DICT || d.kind == PQ_KIND_BOOL_RLE ||
+                                ((d.kind == PQ_KIND_HYBRID || d.kind == PQ_KIND_LEVELS) &&
+                                 (d.flags & (PQ_FLAG_NO_INIT | PQ_FLAG_LEVELS_CONST)) == 0u);
+            return hybrid && d.src_len >= 3 * L && d.src_len < 0x7fffffffull && d.n_values >= 4096u;
         };
         std::stable_partition(g.begin(), g.end(), [&](uint32_t i) { return !cut(i); });
         for (uint32_t i : g) {
@@ -696,6 +700,7 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
         for (int k = 0; k < 2; ++k) r_sr[k] = take(seg_owner[k].size() * sizeof(pq::SegRec));
         const Region r_hr = take(hseg_seg_owner.size() * sizeof(pq::HsegRec));
         const Region r_hn = take(hseg_check_owner.size() * sizeof(uint32_t));
+        const Region r_hx = take(2 * hseg_seg_owner.size() * sizeof(pq::HsegScan));
         const size_t total = img;
         uint8_t *block = nullptr;
         hipError_t e = hipSuccess;
@@ -745,6 +750,7 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
             plan->d_hseg_check_owner = reinterpret_cast<uint32_t *>(block + r_hc.at);
             plan->d_hseg_recs = reinterpret_cast<pq::HsegRec *>(block + r_hr.at);
             plan->d_hseg_counts = reinterpret_cast<uint32_t *>(block + r_hn.at);
+            plan->d_hseg_scans = reinterpret_cast<pq::HsegScan *>(block + r_hx.at);
             plan->d_lowered = reinterpret_cast<uint32_t *>(block + r_low.at);
             put(r_hp, hseg_pages.data());
             put(r_hs, hseg_seg_owner.data());
@@ -828,11 +834,11 @@ static int plan_launch(pq_plan *plan, pq::PageBuffers buf)
     const pq::WaveLaunch wl{ctx->hybrid_wave_min_pages};
     PQ_HIP(ctx, pq::launch_seg_hybrid(ctx->stream, plan->d_descs, plan->d_hseg_pages, plan->n_hseg_pages,
                                       plan->d_hseg_check_owner, plan->n_hseg_checks, plan->d_hseg_counts,
-                                      plan->d_hseg_seg_owner, plan->n_hseg_segs, plan->d_hseg_recs, buf, plan->d_results,
-                                      plan->dict_lds_bytes));
-    PQ_HIP(ctx, pq::launch_stream_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[0],
-                                        plan->count[0] - plan->n_hseg_pages, buf, plan->d_results, plan->dict_lds_bytes,
-                                        wl));
+                                      plan->d_hseg_seg_owner, plan->n_hseg_segs, plan->d_hseg_recs, plan->d_hseg_scans, buf,
+                                      plan->d_results, plan->dict_lds_bytes));
+    PQ_HIP(ctx, pq::launch_stream_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[0], plan->count[0], buf,
+                                        plan->d_results, plan->dict_lds_bytes, wl, plan->d_hseg_pages,
+                                        plan->n_hseg_pages));
     plan->epoch += 1;
     if (plan->epoch == 0) plan->epoch = 1; // 0 is what the flag words start as
     bool serial32 = false, serial64 = false;

@@ -194,10 +194,13 @@ __global__ __launch_bounds__(kWG) void stream_pages_kernel(const pq_page_desc *_
                                                            const uint32_t *__restrict__ ids,
                                                            PageBuffers buf,
                                                            pq_page_result *__restrict__ results,
-                                                           uint32_t dict_lds_bytes)
+                                                           uint32_t dict_lds_bytes,
+                                                           const HsegPage *__restrict__ hseg_pages, uint32_t n_plain)
 {
     HybridShared &sh = *reinterpret_cast<HybridShared *>(pq_smem);
     uint32_t *ldict = reinterpret_cast<uint32_t *>(pq_smem + align16(sizeof(HybridShared)));
+    // a stream the segmented decode has taken care of
+    if (blockIdx.x >= n_plain && hseg_pages[blockIdx.x - n_plain].mode != 0u) return;
     const uint32_t page = ids[blockIdx.x];
     const pq_page_desc d = descs[page];
     const uint8_t *S = buf.src + d.src_off;
@@ -697,7 +700,8 @@ __device__ __forceinline__ HybridResult bool_values_wave(HybridWaveLds &L, const
 __global__ __launch_bounds__(kHwWG) void stream_wave_kernel(const pq_page_desc *__restrict__ descs,
                                                           const uint32_t *__restrict__ ids, uint32_t count,
                                                           PageBuffers buf, pq_page_result *__restrict__ results,
-                                                          uint32_t dict_lds_bytes)
+                                                          uint32_t dict_lds_bytes,
+                                                          const HsegPage *__restrict__ hseg_pages, uint32_t n_plain)
 {
     HybridWaveLds *LW = reinterpret_cast<HybridWaveLds *>(pq_smem);
     uint32_t *lds_dict = reinterpret_cast<uint32_t *>(pq_smem + align16((uint32_t)sizeof(HybridWaveLds) * (kHwWaves)));
@@ -706,6 +710,8 @@ __global__ __launch_bounds__(kHwWG) void stream_wave_kernel(const pq_page_desc *
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t slot = blockIdx.x * (kHwWaves) + (uint32_t)wave;
     if (slot >= count) return;
+    // a stream the segmented decode has taken care of
+    if (slot >= n_plain && uni(hseg_pages[slot - n_plain].mode) != 0u) return;
     HybridWaveLds &L = LW[wave];
     const uint32_t page = ids[slot];
     const pq_page_desc d = descs[page];
@@ -1095,20 +1101,22 @@ static hipError_t allow_lds(K kernel, size_t bytes)
 
 hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
                                uint32_t count, PageBuffers buf, pq_page_result *d_results,
-                               uint32_t dict_lds_bytes, const WaveLaunch &wl)
+                               uint32_t dict_lds_bytes, const WaveLaunch &wl, const HsegPage *d_hseg_pages,
+                               uint32_t n_hseg)
 {
     if (count == 0) return hipSuccess;
+    const uint32_t n_plain = count - n_hseg;
     if (count >= wl.min_pages) {
         const uint32_t grid = (count + kHwWaves - 1) / kHwWaves;
         const hipError_t e = allow_lds(stream_wave_kernel, wave_lds_bytes(dict_lds_bytes));
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(stream_wave_kernel, dim3(grid), dim3(kHwWG), wave_lds_bytes(dict_lds_bytes), s, d_descs,
-                           d_ids, count, buf, d_results, dict_lds_bytes);
+                           d_ids, count, buf, d_results, dict_lds_bytes, d_hseg_pages, n_plain);
         return hipGetLastError();
     }
     const size_t shmem = align16(sizeof(HybridShared)) + dict_lds_bytes;
     hipLaunchKernelGGL(stream_pages_kernel, dim3(count), dim3(kWG), shmem, s, d_descs, d_ids, buf, d_results,
-                       dict_lds_bytes);
+                       dict_lds_bytes, d_hseg_pages, n_plain);
     return hipGetLastError();
 }
 

@@ -30,9 +30,13 @@ struct WaveLaunch {
 // ids: device array of `count` descriptor indices handled by this launch.
 // dict_lds_bytes: LDS set aside per workgroup for a copy of a dictionary (0 = gather from global):
 // the largest dictionary of the plan that fits kDictLdsMax.
+// The last n_hseg of the ids are the streams launch_seg_hybrid looked at before, in the order of
+// d_hseg_pages: those it cut (mode != 0) are done, the others are decoded here.
+struct HsegPage;
 hipError_t launch_stream_pages(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids,
                                uint32_t count, PageBuffers buf, pq_page_result *d_results,
-                               uint32_t dict_lds_bytes, const WaveLaunch &wl);
+                               uint32_t dict_lds_bytes, const WaveLaunch &wl, const HsegPage *d_hseg_pages,
+                               uint32_t n_hseg);
 // wave_min_pages: from this many pages on, the one-wave-per-page kernel runs first and a
 // sweep kernel (woken through *d_flag == epoch) finishes the pages it declined.
 // *needs_serial: launch_delta_serial must follow for these descriptors.
@@ -107,8 +111,9 @@ hipError_t launch_seg_delta(hipStream_t s, int bits, const pq_page_desc *d_descs
                             pq_page_result *d_results, uint32_t *d_flag, uint32_t epoch);
 
 // ---- segmented hybrid streams (seghybrid.hip) ---------------------------------------------------
-// One record per dictionary-index / raw hybrid page that is cut into segments.  The host fills the
-// first six fields; the rest is written on the device every run.
+// One record per hybrid stream (dictionary-index page, level stream, BOOLEAN RLE values, raw stream)
+// that may be cut into segments.  The host fills the first six fields; the rest is written on the
+// device every run.
 struct HsegPage {
     uint32_t desc;         // index of the page's descriptor
     uint32_t seg_first;    // index of its first segment record
@@ -116,15 +121,20 @@ struct HsegPage {
     uint32_t seg_bytes;    // bytes of the stream a segment aims at
     uint32_t check_first;  // index of its first run-check counter
     uint32_t n_checks;     // counters it owns (64 runs each)
-    uint32_t whole;        // 1: not a chain of equal bit-packed runs, segment 0 decodes the whole page
+    uint32_t mode;         // 0: not cut, the one-wave-per-stream kernel decodes it; 1: a chain of equal
+                           // bit-packed runs; 2: runs of any kind
     uint32_t w;            // bit width
-    uint32_t pos0;         // stream offset of the first run header
-    uint32_t stride;       // bytes from one run header to the next
-    uint32_t vpr;          // values per run
-    uint32_t head;         // the run header's bytes
+    uint32_t pos0;         // offset of the first run header from the descriptor's first byte
+    uint32_t end;          // offset of the end of the stream
+    uint32_t stride;       // mode 1: bytes from one run header to the next
+    uint32_t vpr;          // mode 1: values per run
+    uint32_t head;         // mode 1: the run header's bytes
     uint32_t hl;           // and how many they are
     uint32_t runs_per_seg;
-    uint32_t n_part;       // segments of proven runs; the tail is segment n_part
+    uint32_t n_part;       // segments decoded apart from the tail; the tail is segment n_part
+    uint32_t kind_mode;    // HY_RAW, HY_DICT or HY_LEVELS: what the decode does with a value
+    uint32_t max_level;    // HY_LEVELS
+    uint32_t fixed_consumed;  // != 0xffffffff: the consumed bytes the result reports (InitSize, buffered Init)
     uint32_t pad;
 };
 struct HsegRec {
@@ -134,14 +144,24 @@ struct HsegRec {
     uint32_t flags;      // kSeg*
     int32_t status;      // what its decode returned
     uint32_t n_decoded;
-    uint32_t pad;
+    uint32_t count_max;  // HY_LEVELS: values equal to the maximum level
     uint64_t consumed;
+    uint32_t len;        // bytes of the stream it may read
+    uint32_t pad;
 };
-// d_check_owner / d_seg_owner: counter -> page and segment -> page maps.
+// Mode 2: what a walk over the headers of one segment found.
+struct HsegScan {
+    uint32_t entry;  // offset of the first run header at or behind the segment's first byte
+    uint32_t exit;   // offset of the first run header at or behind its end (0xffffffff: the walk ran into
+                     // something that is not a complete, well-formed run)
+    uint32_t nvals;  // values of the runs from entry to exit (saturating at 2^31 - 1)
+    uint32_t pad;
+};
+// d_check_owner / d_seg_owner: counter -> page and segment -> page maps.  d_scans: 2 * n_segs records.
 hipError_t launch_seg_hybrid(hipStream_t s, const pq_page_desc *d_descs, HsegPage *d_pages, uint32_t n_pages,
                              const uint32_t *d_check_owner, uint32_t n_checks, uint32_t *d_counts,
-                             const uint32_t *d_seg_owner, uint32_t n_segs, HsegRec *d_recs, PageBuffers buf,
-                             pq_page_result *d_results, uint32_t dict_lds_bytes);
+                             const uint32_t *d_seg_owner, uint32_t n_segs, HsegRec *d_recs, HsegScan *d_scans,
+                             PageBuffers buf, pq_page_result *d_results, uint32_t dict_lds_bytes);
 
 // Level post-processing (assemble.hip).  d_out: ceil(n / 8) * w bytes, 4-byte aligned.
 hipError_t launch_levels_pack(hipStream_t s, const int32_t *d_levels, uint64_t n, int w, uint8_t *d_out);

@@ -345,3 +345,151 @@ def test_hybrid_streams_in_segments_vs_oracle(ctx, seg_bytes):
     finally:
         ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 1024)
         ctx.set_option(K.OPT_SEGMENT_BYTES, 0)
+
+
+# ---------------------------------------------------------------------------
+# hybrid streams of runs of any kind in segments: level streams, BOOLEAN RLE, run-heavy keys
+
+def _runs(rng, n, hi, mean):
+    """Values in runs of geometric length (mean `mean`), the way level streams and sorted keys look."""
+    out = np.empty(n, dtype=np.int64)
+    i = 0
+    while i < n:
+        ln = int(rng.geometric(1.0 / mean))
+        out[i:i + ln] = rng.integers(0, hi)
+        i += ln
+    return out
+
+
+def _check_run_stream(c):
+    r = c.result
+    if c.kind == K.KIND_LEVELS:
+        mode = 1 if c.flags & K.FLAG_LENGTH_PREFIXED else 2
+        want = O.levels_decode(c.src[: c.result_src_len], c.max_def, c.n, mode)
+        assert r["status"] == want["status"], (c.tag, r, want["status"])
+        assert r["not_null"] == want["not_null"], (c.tag, r, want["not_null"])
+        if want["status"] == O.OK:
+            assert r["n_decoded"] == c.n and np.array_equal(c.def_levels, want["levels"]), c.tag
+            assert r["consumed"] == want["consumed"], (c.tag, r, want["consumed"])
+        assert guard_ok(c.def_guard), c.tag
+        return
+    if c.kind == K.KIND_DICT:
+        st, want, nd, consumed = O.dict_decode(c.src[: c.result_src_len], c.dictionary, c.n)
+    else:
+        w = 1 if c.kind == K.KIND_BOOL_RLE else c.bit_width
+        prefixed = c.kind == K.KIND_BOOL_RLE or bool(c.flags & K.FLAG_LENGTH_PREFIXED)
+        st, want, consumed = O.hybrid_decode(c.src[: c.result_src_len], w, c.n, prefixed)
+        nd = want.size
+    assert r["status"] == st, (c.tag, r, st, nd)
+    assert r["n_decoded"] == nd, (c.tag, r, nd)
+    if st != K.DICT_INVALID_INDEX:
+        assert np.array_equal(c.values[:nd], want[:nd]), c.tag
+    assert guard_ok(c.guard), c.tag
+    if st == O.OK:
+        assert r["consumed"] == consumed, (c.tag, r, consumed)
+
+
+def _run_stream_cases(rng):
+    cases = []
+
+    def add(tag, kind, stream, n, **kw):
+        c = Case(kind, stream, n, **kw)
+        c.result_src_len = c.src.size
+        c.tag = tag
+        cases.append(c)
+        return c
+    d32 = rng.integers(-2**31, 2**31, size=4096, dtype=np.int64).astype(np.int32)
+    n = 400_000
+    # level streams the way a nested column has them: repetition levels (w = 1), definition levels (w = 2, 3)
+    for max_level, p in ((1, 0.75), (3, 0.8), (7, 0.5)):
+        lv = np.where(rng.random(n) < p, max_level, rng.integers(0, max_level + 1, size=n))
+        s = synth.hybrid_encode(lv, int(max_level).bit_length())
+        for pull in (n, n - 1, n // 2 + 3, 4096, n + 9):
+            add("levels max %d raw pull %d" % (max_level, pull), K.KIND_LEVELS, s, pull, max_def=max_level)
+        add("levels max %d prefixed" % max_level, K.KIND_LEVELS, synth.length_prefixed(s), n, max_def=max_level,
+            flags=K.FLAG_LENGTH_PREFIXED)
+        # a length prefix that says less than there is, one that says more
+        short = synth.length_prefixed(s).copy()
+        short[:4] = np.frombuffer(np.uint32(s.size // 2).tobytes(), np.uint8)
+        add("levels max %d prefix says half" % max_level, K.KIND_LEVELS, short, n, max_def=max_level,
+            flags=K.FLAG_LENGTH_PREFIXED)
+        for cut in (s.size - 1, s.size - 100, s.size // 2, s.size // 3 + 1, 20000):
+            add("levels max %d cut %d" % (max_level, cut), K.KIND_LEVELS, s[:cut].copy(), n, max_def=max_level)
+    # long constant stretches: RLE runs with headers of three and four bytes
+    lv = np.concatenate([np.full(50_000, 2), _runs(rng, 100_000, 3, 6), np.full(300_000, 1), _runs(rng, 100_000, 3, 3),
+                         np.full(3_000_000, 2), _runs(rng, 60_000, 3, 10)])
+    s = synth.hybrid_encode(lv, 2)
+    add("levels long runs", K.KIND_LEVELS, s, lv.size, max_def=2)
+    add("levels long runs, pull inside a long run", K.KIND_LEVELS, s, 1_000_000, max_def=2)
+    # BOOLEAN RLE values and length-prefixed raw streams
+    for mean in (3, 24, 300):
+        bits = _runs(rng, n, 2, mean)
+        s = synth.length_prefixed(synth.hybrid_encode(bits, 1))
+        add("bool rle mean run %d" % mean, K.KIND_BOOL_RLE, s, n)
+        add("bool rle mean run %d cut" % mean, K.KIND_BOOL_RLE, s[: s.size * 2 // 3].copy(), n)
+        add("hybrid w=1 prefixed mean run %d" % mean, K.KIND_HYBRID, s, n, bit_width=1, flags=K.FLAG_LENGTH_PREFIXED)
+    # run-heavy dictionary keys (bit-packed groups between RLE runs), also at widths whose RLE value takes 3 and 4 bytes
+    keys = _runs(rng, n, 4096, 32)
+    page = synth.dict_page(keys, w=12)
+    for pull in (n, n // 3, n + 1):
+        add("dict run-heavy pull %d" % pull, K.KIND_DICT, page, pull, dictionary=d32)
+    for cut in (page.size - 1, page.size // 2, page.size // 5):
+        add("dict run-heavy cut %d" % cut, K.KIND_DICT, page[:cut].copy(), n, dictionary=d32)
+    bad = keys.copy()
+    bad[n // 2] = 4095
+    add("dict run-heavy invalid index", K.KIND_DICT, synth.dict_page(bad, w=12), n, dictionary=d32[:4000])
+    for w in (5, 17, 20, 27, 32):
+        v = _runs(rng, 150_000, 1 << min(w, 31), 12)
+        add("hybrid w=%d runs" % w, K.KIND_HYBRID, synth.hybrid_encode(v, w), v.size, bit_width=w)
+    # chains that never fall into step: every byte parses as "one repeat of the value 2" wherever a walk starts
+    twos = np.full(60_000, 2, dtype=np.uint8)
+    add("hybrid w=8 all 02", K.KIND_HYBRID, twos, 30_000, bit_width=8)
+    add("hybrid w=8 all 02, odd length", K.KIND_HYBRID, twos[:-1].copy(), 29_999, bit_width=8)
+    # ... and the real chain on the odd bytes (behind a dictionary page's width byte), where no guess lands
+    add("dict w=8 all 02", K.KIND_DICT, np.concatenate([[8], twos]).astype(np.uint8), 30_000, dictionary=d32[:256])
+    # damage in the middle: an empty run, a run value too large, random bytes from some point on
+    lv = np.where(rng.random(n) < 0.8, 3, rng.integers(0, 4, size=n))
+    s = synth.hybrid_encode(lv, 2)
+    for at, val in ((s.size // 2, 0x00), (s.size // 2, 0x01), (s.size // 3, 0x80)):
+        t = s.copy()
+        t[at: at + 3] = val
+        add("levels damaged at %d with %#x" % (at, val), K.KIND_LEVELS, t, n, max_def=3)
+    t = s.copy()
+    t[t.size // 2:] = rng.integers(0, 256, size=t.size - t.size // 2, dtype=np.uint8)
+    add("levels random second half", K.KIND_LEVELS, t, n, max_def=3)
+    add("hybrid w=2 random second half", K.KIND_HYBRID, t, n, bit_width=2)
+    return cases
+
+
+def _say(what):
+    """Names the GPU step that comes next (a run that stalls is then known by its last line)."""
+    import os
+    print(what, flush=True)
+    if os.path.isdir("gpurun_out"):
+        with open("gpurun_out/segments_progress.log", "a") as f:
+            f.write(what + "\n")
+
+
+@pytest.mark.parametrize("seg_bytes", [2048, 4096, 0])
+def test_run_streams_in_segments_vs_oracle(ctx, seg_bytes):
+    rng = np.random.default_rng(1300 + seg_bytes)
+    cases = _run_stream_cases(rng)
+    families = {}
+    for c in cases:                             # one plan per family of cases
+        families.setdefault(" ".join(c.tag.split()[:2]), []).append(c)
+    try:
+        for max_pages in (0, 1 << 30):          # not cut at all, and cut into segments
+            ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, max_pages)
+            ctx.set_option(K.OPT_SEGMENT_BYTES, seg_bytes)
+            for name, group in families.items():
+                _say("run streams: seg_bytes %d, max_pages %d, %s (%d cases)" % (seg_bytes, max_pages, name, len(group)))
+                run_cases(ctx, group, seed=13)
+                for c in group:
+                    _check_run_stream(c)
+            _say("run streams: seg_bytes %d, max_pages %d, all in one plan" % (seg_bytes, max_pages))
+            run_cases(ctx, cases, seed=13)
+            for c in cases:
+                _check_run_stream(c)
+    finally:
+        ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 1024)
+        ctx.set_option(K.OPT_SEGMENT_BYTES, 0)
