@@ -629,23 +629,32 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
             L = 8192;
             while (L < 65536 && L * 16384 < bytes) L *= 2;
         }
+        // A run-dense stream (levels, run-heavy keys) holds many values per byte, and the work of a
+        // segment goes by its values: such a page gets shorter segments, about 8192 values each.
+        auto seg_len = [&](uint32_t i) -> uint64_t {
+            const pq_page_desc &d = descs[i];
+            if (ctx->seg_bytes != 0 || d.n_values == 0) return L;
+            const uint64_t by_values = (8192ull * d.src_len / d.n_values + 15u) & ~15ull;
+            return std::min<uint64_t>(L, std::max<uint64_t>(by_values, 1024u));
+        };
         auto cut = [&](uint32_t i) {
             const pq_page_desc &d = descs[i];
             // every kind that is a hybrid stream with a reader behind it (hseg_header_kernel looks closer)
             const bool hybrid = d.kind == PQ_KIND_DICT || d.kind == PQ_KIND_BOOL_RLE ||
                                 ((d.kind == PQ_KIND_HYBRID || d.kind == PQ_KIND_LEVELS) &&
                                  (d.flags & (PQ_FLAG_NO_INIT | PQ_FLAG_LEVELS_CONST)) == 0u);
-            return hybrid && d.src_len >= 3 * L && d.src_len < 0x7fffffffull && d.n_values >= 4096u;
+            return hybrid && d.src_len >= 3 * seg_len(i) && d.src_len < 0x7fffffffull && d.n_values >= 4096u;
         };
         std::stable_partition(g.begin(), g.end(), [&](uint32_t i) { return !cut(i); });
         for (uint32_t i : g) {
             if (!cut(i)) continue;
+            const uint64_t Lp = seg_len(i);
             pq::HsegPage pg;
             std::memset(&pg, 0, sizeof pg);
             pg.desc = i;
             pg.seg_first = (uint32_t)hseg_seg_owner.size();
-            pg.n_segs = (uint32_t)(2 * ((descs[i].src_len + L - 1) / L) + 2);
-            pg.seg_bytes = (uint32_t)L;
+            pg.n_segs = (uint32_t)(2 * ((descs[i].src_len + Lp - 1) / Lp) + 2);
+            pg.seg_bytes = (uint32_t)Lp;
             pg.check_first = (uint32_t)hseg_check_owner.size();
             pg.n_checks = (uint32_t)((descs[i].src_len + 4095) / 4096);
             hseg_seg_owner.insert(hseg_seg_owner.end(), pg.n_segs, (uint32_t)hseg_pages.size());

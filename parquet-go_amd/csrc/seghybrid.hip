@@ -22,7 +22,7 @@
 //                       the chain enters the segment, where it leaves it and how many values the
 //                       runs in between hold.  A guess: nothing is decoded from it.
 //   lseg_fix_kernel     one wave per segment: where the segment in front left at another place than
-//                       this one entered at, walks this one again from there.
+//                       this one entered at, walks this one again from there.  Two rounds.
 //   lseg_link_kernel    one wave per page: segment 0 starts at the true first header; segment s + 1
 //                       is proven iff segment s is and left where s + 1 entered.  Prefix sums of the
 //                       value counts give every proven segment its first value's index.  A link
@@ -42,9 +42,10 @@ namespace pq {
 constexpr int kHsWG = 512;               // threads per workgroup of the decode kernel
 constexpr int kHsWaves = kHsWG / kWave;  // segments per workgroup
 constexpr uint32_t kHsMinStride = 64;    // shorter runs are not worth a lane each
-constexpr uint32_t kLsPreRoll = 256;     // bytes in front of a segment a scan starts at
+constexpr uint32_t kLsPreRoll = 512;     // bytes in front of a segment a scan starts at
 constexpr uint32_t kLsGuard = 80;        // a span parse reads 64 + 12 bytes from its first byte on
-constexpr uint32_t kLsRepairs = 16;      // broken links per page the link pass walks again itself
+constexpr uint32_t kLsRepairs = 1024;    // broken links per page the link pass walks again itself (a walk costs a
+                                         // tenth of a decode: still far better than leaving the rest to the tail)
 constexpr uint32_t kLsNone = 0xffffffffu;
 
 extern __shared__ __attribute__((aligned(16))) uint8_t pq_hs_smem[];
@@ -287,7 +288,13 @@ __device__ __forceinline__ LsEnd ls_walk(LsWalk &W, uint32_t from, uint32_t boun
         const uint32_t step = hdr + (isbp ? __umul24(cnt, hc.w) : hc.vb);  // bytes of the run: below 2^19
         const uint32_t nvals = isbp ? cnt * 8u : cnt;
         const uint32_t nextlane = (uint32_t)lane + step;
-        const bool ok = (lo & 0x8080u) != 0x8080u && cnt != 0u && o + nextlane <= end && (isbp || (val & ~hc.wmask) == 0u);
+        // In front of a segment (COUNT == false) the walk is looking for the real chain from an arbitrary
+        // byte: a bit-packed run of more than 64 groups is taken for what it almost always is there, a
+        // byte of packed data read as a header (writers close bit-packed runs after 63 or 64 groups),
+        // because following it would jump over the segment's first byte and find nothing.
+        const bool plausible = COUNT || !isbp || cnt <= 64u;
+        const bool ok = (lo & 0x8080u) != 0x8080u && cnt != 0u && o + nextlane <= end && (isbp || (val & ~hc.wmask) == 0u) &&
+                        plausible;
         const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
         // the chain of real headers from lane 0 on (see dn_span for the schedule of this loop)
         uint32_t cur;
@@ -329,6 +336,7 @@ __device__ __forceinline__ LsEnd ls_walk(LsWalk &W, uint32_t from, uint32_t boun
         const int64_t lim64 = W.end - W.c0;
         const uint32_t lim = lim64 > (int64_t)(1 << 30) ? (1u << 30) : (uint32_t)lim64;
         if (!hw_header_fast(st, W.lds, lim, hc.w)) return LsEnd{kLsNone, at};
+        if (!COUNT && st.pend == 2u && st.pcount > 64u) return LsEnd{kLsNone, at};  // see `plausible`
         // the run's end as a 64-bit number: a count of up to 2^27 groups times the width does not fit 32 bits
         uint64_t next = (uint64_t)o + (st.o - wo);
         uint64_t nv = st.pcount;
@@ -685,9 +693,14 @@ hipError_t launch_seg_hybrid(hipStream_t s, const pq_page_desc *d_descs, HsegPag
     hipLaunchKernelGGL(hseg_link_kernel, gp, dim3(kWG), 0, s, d_descs, d_pages, n_pages, d_counts, d_recs);
     // d_scans: two arrays of n_segs records, the second the first after the fix pass
     hipLaunchKernelGGL(lseg_scan_kernel, gs, dim3(kWG), 0, s, d_descs, d_pages, d_seg_owner, n_segs, d_scans, buf);
+    // two rounds: a segment entered at the wrong place usually still leaves at the right one (its walk
+    // falls into step inside it), so the first round sets most entries right and the second the few
+    // whose predecessor's exit was itself wrong at first
     hipLaunchKernelGGL(lseg_fix_kernel, gs, dim3(kWG), 0, s, d_descs, d_pages, d_seg_owner, n_segs, d_scans, d_scans + n_segs,
                        buf);
-    hipLaunchKernelGGL(lseg_link_kernel, gp, dim3(kWG), 0, s, d_descs, d_pages, n_pages, d_scans + n_segs, d_recs, buf);
+    hipLaunchKernelGGL(lseg_fix_kernel, gs, dim3(kWG), 0, s, d_descs, d_pages, d_seg_owner, n_segs, d_scans + n_segs, d_scans,
+                       buf);
+    hipLaunchKernelGGL(lseg_link_kernel, gp, dim3(kWG), 0, s, d_descs, d_pages, n_pages, d_scans, d_recs, buf);
     const size_t lds = hs_align16((uint32_t)sizeof(HybridWaveLds) * kHsWaves) + dict_lds_bytes;
     if (lds > 65536) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(hseg_decode_kernel),

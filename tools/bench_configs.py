@@ -77,11 +77,11 @@ def runny(rng, n, hi, mean_run):
     return out
 
 
-def bench_dict(ctx, stream, pages, n, run_heavy, label):
+def bench_dict(ctx, stream, pages, n, run_heavy, label, distinct_cap=None):
     rng = np.random.default_rng(1)
     d = synth.splitmix64(0xD1C7, 4096).astype(np.uint32).view(np.int32)
     streams, keys_all = [], []
-    distinct = min(pages, 200 if run_heavy else pages)
+    distinct = min(pages, (200 if run_heavy else pages) if distinct_cap is None else distinct_cap)
     for p in range(distinct):
         keys = runny(rng, n, 4096, 32) if run_heavy else rng.integers(0, 4096, size=n)
         keys_all.append(keys)
@@ -172,6 +172,38 @@ def bench_nested(ctx, stream, pages, n, distinct=100):
     plan.close()
 
 
+def bench_levels_stream(ctx, stream, pages, n, max_level, p_max, label, distinct=8):
+    """Bare level streams (PQ_KIND_LEVELS, raw): int32 levels out + the count of levels at the maximum."""
+    rng = np.random.default_rng(12)
+    distinct = min(pages, distinct)
+    streams, want = [], []
+    for _ in range(distinct):
+        lv = np.where(rng.random(n) < p_max, max_level, rng.integers(0, max_level + 1, size=n))
+        streams.append(synth.hybrid_encode(lv, int(max_level).bit_length()))
+        want.append(lv.astype(np.int32))
+    while len(streams) < pages:
+        streams.append(streams[len(streams) % distinct])
+        want.append(want[len(want) % distinct])
+    src, offs, lens = pack_pages(streams)
+    descs = np.zeros(pages, dtype=capi.DESC_DTYPE)
+    descs["kind"] = capi.KIND_LEVELS
+    descs["src_off"], descs["src_len"], descs["n_values"], descs["max_def"] = offs, lens, n, max_level
+    descs["def_off"] = np.arange(pages, dtype=np.uint64) * np.uint64(4 * n)
+    t_src = torch.from_numpy(src).to(DEV)
+    t_lvl = torch.empty(pages * n, dtype=torch.int32, device=DEV)
+    plan = ctx.plan(descs)
+    fn = lambda: plan.run(t_src.data_ptr(), src.size, 0, 0, t_lvl.data_ptr(), pages * n * 4)
+    t = timed(fn, stream, steps=6, warmup=1)
+    res = plan.results()
+    assert (res["status"] == 0).all() and (res["n_decoded"] == n).all()
+    got = t_lvl.view(pages, n)
+    for p in (0, pages // 2, pages - 1):
+        assert np.array_equal(got[p].cpu().numpy(), want[p])
+        assert int(res[p]["not_null"]) == int((want[p] == max_level).sum())
+    report(label, int(lens.sum()), pages * n * 4, t, {"pages": pages, "slots_per_page": n})
+    plan.close()
+
+
 def bench_delta(ctx, stream, pages, n, bits, width, label="", as_pages=False):
     """as_pages: the same streams as PQ_KIND_PAGE_V1 descriptors of a flat REQUIRED column (what
     pq_chunks_page_descs makes of a walked chunk) instead of bare PQ_KIND_DELTA32/64."""
@@ -211,7 +243,7 @@ def bench_delta(ctx, stream, pages, n, bits, width, label="", as_pages=False):
 def bench_plain(ctx, stream, pages, n, kind, es, label):
     """kind: KIND_PLAIN (es bytes per value), KIND_BOOL_PLAIN or KIND_BOOL_RLE (int32 0 / 1 out)."""
     rng = np.random.default_rng(6)
-    distinct = min(pages, 64)
+    distinct = min(pages, 64 if n <= 100_000 else 4)
     streams, want = [], []
     for p in range(distinct):
         if kind == capi.KIND_PLAIN:
@@ -395,6 +427,15 @@ def main():
         bench_nested(ctx, stream, args.pages, 20000)
     if args.only and want("c4big"):   # the large-page variant: 500 pages x 1 M slots (10 distinct pages)
         bench_nested(ctx, stream, 500, 1_000_000, distinct=10)
+    if args.only and want("hybig"):   # few large pages of run-dense hybrid streams: cut into segments against one wave a page
+        for seg in (1024, 0):
+            ctx.set_option(capi.OPT_SEGMENT_MAX_PAGES, seg)
+            lab = ", segmented" if seg else ", one wave per page"
+            bench_levels_stream(ctx, stream, 64, 1_000_000, 3, 0.8, "L def levels (max 3), 64 x 1 M slots" + lab)
+            bench_levels_stream(ctx, stream, 64, 1_000_000, 1, 0.75, "L rep levels (max 1), 64 x 1 M slots" + lab)
+            bench_dict(ctx, stream, 64, 1_000_000, True, "C1b dict w=12 run-heavy keys, 64 x 1 M values" + lab, distinct_cap=4)
+            bench_plain(ctx, stream, 64, 1_000_000, capi.KIND_BOOL_RLE, 4, "P BOOLEAN RLE (mean run 24), 64 x 1 M values" + lab)
+        ctx.set_option(capi.OPT_SEGMENT_MAX_PAGES, 1024)
     if want("c2x"):
         for w in (4, 8, 24, 30, 32):
             bench_delta(ctx, stream, args.pages, 20000, 64, w)
