@@ -67,7 +67,7 @@ struct ChunkSlot {
     size_t off_levels = 0, off_results = 0;
 };
 
-constexpr int kGroups = 6;  // kernel groups of a plan
+constexpr int kGroups = 7;  // kernel groups of a plan (the last: level units of split nested pages)
 
 struct SetNeed {
     uint64_t src = 0, values = 0, levels = 0, dict = 0;
@@ -83,9 +83,9 @@ struct pq_plan {
     uint32_t *d_flags = nullptr; // [0], [32], [64]: sweep wake-up words (delta32, delta64, data pages)
     uint32_t epoch = 0;          // bumped every run; a flag word equal to it is "raised"
     // descriptor ids grouped by kernel:
-    // [stream | delta32 | delta64 | data pages | DELTA_LENGTH_BYTE_ARRAY | DELTA_BYTE_ARRAY]
-    uint32_t count[kGroups] = {0, 0, 0, 0, 0, 0};
-    uint32_t first[kGroups] = {0, 0, 0, 0, 0, 0};
+    // [stream | delta32 | delta64 | data pages | DELTA_LENGTH_BYTE_ARRAY | DELTA_BYTE_ARRAY | level units]
+    uint32_t count[kGroups] = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t first[kGroups] = {0, 0, 0, 0, 0, 0, 0};
     uint32_t dict_lds_bytes = 0;  // the largest dictionary that fits LDS: what a workgroup sets aside for its copy
     bool has_delta_page = false; // some PAGE_V1/V2 descriptor carries delta values
     // delta32 / delta64 descriptors that are decoded in segments: the last n_seg_pages[k] ids of
@@ -95,12 +95,20 @@ struct pq_plan {
     pq::SegPage *d_seg_pages[2] = {nullptr, nullptr};
     uint32_t *d_seg_owner[2] = {nullptr, nullptr};
     pq::SegRec *d_seg_recs[2] = {nullptr, nullptr};
-    // hybrid / dictionary descriptors decoded in segments: the last n_hseg_pages ids of group 0
-    uint32_t n_hseg_pages = 0, n_hseg_segs = 0, n_hseg_checks = 0;
-    pq::HsegPage *d_hseg_pages = nullptr;
-    uint32_t *d_hseg_seg_owner = nullptr, *d_hseg_check_owner = nullptr, *d_hseg_counts = nullptr;
-    pq::HsegRec *d_hseg_recs = nullptr;
-    pq::HsegScan *d_hseg_scans = nullptr;  // two records per segment
+    // hybrid streams that may be decoded in segments: [0] the last hs[0].n_pages ids of group 0, [1] the
+    // level units of split nested pages (group 6, all of them candidates)
+    struct HsegDev {
+        uint32_t n_pages = 0, n_segs = 0, n_checks = 0;
+        pq::HsegPage *d_pages = nullptr;
+        uint32_t *d_seg_owner = nullptr, *d_check_owner = nullptr, *d_counts = nullptr;
+        pq::HsegRec *d_recs = nullptr;
+        pq::HsegScan *d_scans = nullptr;  // two records per segment
+    } hs[2];
+    // large pages of nested columns run as three units each (nested.hip): the internal table holds
+    // n_total = n + 2 * n_split descriptors and results, the caller sees the first n
+    size_t n_total = 0;
+    uint32_t n_split = 0;
+    pq::NestedPage *d_npages = nullptr;
     // data pages of flat columns that are decoded as the value streams they hold (see lower_flat_page):
     // their ids, and whether any of them wants its constant levels written out
     uint32_t n_lowered = 0;
@@ -196,6 +204,7 @@ uint32_t value_size(const pq_page_desc &d)
 // turns the stream's result into the page's (page-v1.go:80-116).  Pages that decode no value
 // (max_def != 0: the constant level 0 never equals it), empty pages and V2 pages whose level bytes
 // are not all there stay with the page kernels.
+constexpr uint32_t kNestedSplitMin = 65536;  // level slots from which a nested page is worth three units
 constexpr uint32_t kFlagLowered = 0x80000000u;  // internal: never set by callers (validate refuses it)
 
 bool lower_flat_page(pq_page_desc &d)
@@ -561,6 +570,63 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
     plan->n_lowered = (uint32_t)lowered.size();
     plan->dict_lds_bytes = (uint32_t)((dict_bytes_max + 15u) & ~15ull);
 
+    // Few large pages of nested columns: each becomes three units of work — its repetition levels,
+    // its definition levels (two level streams appended to the table) and its values (the page's own
+    // slot, turned into a stream of the value encoding) — whose places and counts are filled in on
+    // the device at every run (nested.hip).
+    std::vector<pq::NestedPage> npages;
+    std::vector<uint64_t> level_bound;  // per appended unit: an upper estimate of its stream's bytes
+    if (!ids[3].empty() && ids[3].size() < ctx->seg_max_pages) {
+        std::vector<uint32_t> keep;
+        for (uint32_t i : ids[3]) {
+            const pq_page_desc page = descs[i];
+            if (page.max_rep == 0 || page.n_values < kNestedSplitMin || page.src_len >= 0x7fffffffull) {
+                keep.push_back(i);
+                continue;
+            }
+            pq::NestedPage np;
+            std::memset(&np, 0, sizeof np);
+            np.desc = i;
+            np.rep_unit = (uint32_t)descs.size();
+            np.def_unit = np.rep_unit + 1u;
+            np.version = page.kind == PQ_KIND_PAGE_V1 ? 1u : 2u;
+            np.rep_len = page.rep_len;
+            np.def_len = page.def_len;
+            np.max_rep = page.max_rep;
+            np.max_def = page.max_def;
+            np.n_values = page.n_values;
+            npages.push_back(np);
+            for (int k = 0; k < 2; ++k) {
+                pq_page_desc u;
+                std::memset(&u, 0, sizeof u);
+                u.kind = PQ_KIND_LEVELS;
+                u.src_off = page.src_off;
+                u.src_len = page.src_len;
+                u.n_values = page.n_values;
+                u.max_def = k == 0 ? page.max_rep : page.max_def;
+                u.def_off = k == 0 ? page.rep_off : page.def_off;
+                uint32_t w = 0;  // bits.Len16 of the maximum level
+                for (uint32_t m = u.max_def & 0xffffu; m != 0u; m >>= 1) ++w;
+                // V2 headers say how long the level sections are; for V1 one and a half times what plain
+                // bit-packing would take (a stream that turns out longer is finished by its tail segment)
+                uint64_t bound = np.version == 2u ? (k == 0 ? page.rep_len : page.def_len)
+                                                  : (uint64_t)page.n_values * w / 8u * 3u / 2u + 1024u;
+                level_bound.push_back(std::min<uint64_t>(bound, page.src_len));
+                ids[6].push_back((uint32_t)descs.size());
+                if (n_sets > 1) set_of.push_back(set_of[i]);
+                descs.push_back(u);
+            }
+            pq_page_desc &v = descs[i];  // the value unit: place and count are set on the device
+            v.kind = page.value_kind;
+            v.flags = 0;
+            ids[group_of(v)].push_back(i);
+        }
+        ids[3].swap(keep);
+    }
+    plan->n_split = (uint32_t)npages.size();
+    const size_t n_total = descs.size();
+    plan->n_total = n_total;
+
     if (hipSetDevice(ctx->device) != hipSuccess) {
         delete plan;
         return PQ_ERR_HIP;
@@ -576,8 +642,8 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
         const uint32_t b = 63u - (uint32_t)__builtin_clzll(w);
         return 2u * b + (b ? (uint32_t)((w >> (b - 1u)) & 1u) : 0u);
     };
-    std::vector<uint8_t> bucket(n_pages);
-    for (size_t i = 0; i < n_pages; ++i) bucket[i] = (uint8_t)work_bucket((uint32_t)i);
+    std::vector<uint8_t> bucket(n_total);
+    for (size_t i = 0; i < n_total; ++i) bucket[i] = (uint8_t)work_bucket((uint32_t)i);
     for (int g = 0; g < kGroups; ++g) {
         bool mixed = false;
         for (uint32_t i : ids[g]) mixed = mixed || bucket[i] != bucket[ids[g][0]];
@@ -617,11 +683,14 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
         plan->n_seg_pages[k] = (uint32_t)seg_pages[k].size();
         plan->n_segs[k] = (uint32_t)seg_owner[k].size();
     }
-    // The same for dictionary-index pages and raw hybrid streams (seghybrid.hip).
-    std::vector<pq::HsegPage> hseg_pages;
-    std::vector<uint32_t> hseg_seg_owner, hseg_check_owner;
-    if (!ids[0].empty() && ids[0].size() < ctx->seg_max_pages) {
-        std::vector<uint32_t> &g = ids[0];
+    // The same for hybrid streams (seghybrid.hip): dictionary-index pages, level streams, BOOLEAN RLE
+    // values and raw streams of group 0, and the level units of split nested pages.
+    struct HsegHost {
+        std::vector<pq::HsegPage> pages;
+        std::vector<uint32_t> seg_owner, check_owner;
+    } hsh[2];
+    auto build_hseg = [&](std::vector<uint32_t> &g, HsegHost &out, bool units) {
+        if (g.empty() || (!units && g.size() >= ctx->seg_max_pages)) return;
         uint64_t bytes = 0;
         for (uint32_t i : g) bytes += descs[i].src_len;
         uint64_t L = ctx->seg_bytes;
@@ -629,15 +698,20 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
             L = 8192;
             while (L < 65536 && L * 16384 < bytes) L *= 2;
         }
+        // what the stream is expected to hold: the descriptor's bytes, for a level unit its estimate
+        auto stream_bytes = [&](uint32_t i) -> uint64_t {
+            return units ? level_bound[i - n_pages] : descs[i].src_len;
+        };
         // A run-dense stream (levels, run-heavy keys) holds many values per byte, and the work of a
         // segment goes by its values: such a page gets shorter segments, about 8192 values each.
         auto seg_len = [&](uint32_t i) -> uint64_t {
             const pq_page_desc &d = descs[i];
             if (ctx->seg_bytes != 0 || d.n_values == 0) return L;
-            const uint64_t by_values = (8192ull * d.src_len / d.n_values + 15u) & ~15ull;
+            const uint64_t by_values = (8192ull * stream_bytes(i) / d.n_values + 15u) & ~15ull;
             return std::min<uint64_t>(L, std::max<uint64_t>(by_values, 1024u));
         };
         auto cut = [&](uint32_t i) {
+            if (units) return true;  // all of them: their places are only known on the device
             const pq_page_desc &d = descs[i];
             // every kind that is a hybrid stream with a reader behind it (hseg_header_kernel looks closer)
             const bool hybrid = d.kind == PQ_KIND_DICT || d.kind == PQ_KIND_BOOL_RLE ||
@@ -648,25 +722,29 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
         std::stable_partition(g.begin(), g.end(), [&](uint32_t i) { return !cut(i); });
         for (uint32_t i : g) {
             if (!cut(i)) continue;
-            const uint64_t Lp = seg_len(i);
+            const uint64_t Lp = seg_len(i), sb = stream_bytes(i);
             pq::HsegPage pg;
             std::memset(&pg, 0, sizeof pg);
             pg.desc = i;
-            pg.seg_first = (uint32_t)hseg_seg_owner.size();
-            pg.n_segs = (uint32_t)(2 * ((descs[i].src_len + Lp - 1) / Lp) + 2);
+            pg.seg_first = (uint32_t)out.seg_owner.size();
+            pg.n_segs = (uint32_t)(2 * ((sb + Lp - 1) / Lp) + 2);
             pg.seg_bytes = (uint32_t)Lp;
-            pg.check_first = (uint32_t)hseg_check_owner.size();
-            pg.n_checks = (uint32_t)((descs[i].src_len + 4095) / 4096);
-            hseg_seg_owner.insert(hseg_seg_owner.end(), pg.n_segs, (uint32_t)hseg_pages.size());
-            hseg_check_owner.insert(hseg_check_owner.end(), pg.n_checks, (uint32_t)hseg_pages.size());
-            hseg_pages.push_back(pg);
+            pg.check_first = (uint32_t)out.check_owner.size();
+            pg.n_checks = units ? 0u : (uint32_t)((sb + 4095) / 4096);  // level streams are never chains of equal runs
+            out.seg_owner.insert(out.seg_owner.end(), pg.n_segs, (uint32_t)out.pages.size());
+            out.check_owner.insert(out.check_owner.end(), pg.n_checks, (uint32_t)out.pages.size());
+            out.pages.push_back(pg);
         }
-        plan->n_hseg_pages = (uint32_t)hseg_pages.size();
-        plan->n_hseg_segs = (uint32_t)hseg_seg_owner.size();
-        plan->n_hseg_checks = (uint32_t)hseg_check_owner.size();
+    };
+    build_hseg(ids[0], hsh[0], false);
+    build_hseg(ids[6], hsh[1], true);
+    for (int k = 0; k < 2; ++k) {
+        plan->hs[k].n_pages = (uint32_t)hsh[k].pages.size();
+        plan->hs[k].n_segs = (uint32_t)hsh[k].seg_owner.size();
+        plan->hs[k].n_checks = (uint32_t)hsh[k].check_owner.size();
     }
     std::vector<uint32_t> all;
-    all.reserve(n_pages);
+    all.reserve(n_total);
     for (int g = 0; g < kGroups; ++g) {
         plan->first[g] = (uint32_t)all.size();
         plan->count[g] = (uint32_t)ids[g].size();
@@ -688,28 +766,37 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
             return r;
         };
         constexpr size_t kFlagBytes = 512;
-        const Region r_descs = take(n_pages * sizeof(pq_page_desc)), r_ids = take(n_pages * sizeof(uint32_t));
+        const Region r_descs = take(n_total * sizeof(pq_page_desc)), r_ids = take(n_total * sizeof(uint32_t));
         const Region r_flags = take(kFlagBytes);
         Region r_sp[2], r_so[2];
         for (int k = 0; k < 2; ++k) {
             r_sp[k] = take(seg_pages[k].size() * sizeof(pq::SegPage));
             r_so[k] = take(seg_owner[k].size() * sizeof(uint32_t));
         }
-        const Region r_hp = take(hseg_pages.size() * sizeof(pq::HsegPage));
-        const Region r_hs = take(hseg_seg_owner.size() * sizeof(uint32_t));
-        const Region r_hc = take(hseg_check_owner.size() * sizeof(uint32_t));
+        Region r_hp[2], r_hs[2], r_hc[2];
+        for (int k = 0; k < 2; ++k) {
+            r_hp[k] = take(hsh[k].pages.size() * sizeof(pq::HsegPage));
+            r_hs[k] = take(hsh[k].seg_owner.size() * sizeof(uint32_t));
+            r_hc[k] = take(hsh[k].check_owner.size() * sizeof(uint32_t));
+        }
         const Region r_low = take(lowered.size() * sizeof(uint32_t));
         const Region r_set = take(set_of.size() * sizeof(uint32_t));
-        // several buffer sets: the table as created stays here, every run derives r_descs from it
-        const Region r_descs0 = take(n_sets > 1 ? n_pages * sizeof(pq_page_desc) : 0);
+        const Region r_np = take(npages.size() * sizeof(pq::NestedPage));
+        // several buffer sets, or descriptors the device rewrites: the table as created stays here,
+        // every run derives r_descs from it
+        const bool keep_table = n_sets > 1 || !npages.empty();
+        const Region r_descs0 = take(keep_table ? n_total * sizeof(pq_page_desc) : 0);
         const size_t img_bytes = img;
         const Region r_deltas = take(n_sets > 1 ? n_sets * 4 * sizeof(uint64_t) : 0);
-        const Region r_res = take(n_pages * sizeof(pq_page_result));
+        const Region r_res = take(n_total * sizeof(pq_page_result));
         Region r_sr[2];
         for (int k = 0; k < 2; ++k) r_sr[k] = take(seg_owner[k].size() * sizeof(pq::SegRec));
-        const Region r_hr = take(hseg_seg_owner.size() * sizeof(pq::HsegRec));
-        const Region r_hn = take(hseg_check_owner.size() * sizeof(uint32_t));
-        const Region r_hx = take(2 * hseg_seg_owner.size() * sizeof(pq::HsegScan));
+        Region r_hr[2], r_hn[2], r_hx[2];
+        for (int k = 0; k < 2; ++k) {
+            r_hr[k] = take(hsh[k].seg_owner.size() * sizeof(pq::HsegRec));
+            r_hn[k] = take(hsh[k].check_owner.size() * sizeof(uint32_t));
+            r_hx[k] = take(2 * hsh[k].seg_owner.size() * sizeof(pq::HsegScan));
+        }
         const size_t total = img;
         uint8_t *block = nullptr;
         hipError_t e = hipSuccess;
@@ -754,23 +841,30 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
                 put(r_sp[k], seg_pages[k].data());
                 put(r_so[k], seg_owner[k].data());
             }
-            plan->d_hseg_pages = reinterpret_cast<pq::HsegPage *>(block + r_hp.at);
-            plan->d_hseg_seg_owner = reinterpret_cast<uint32_t *>(block + r_hs.at);
-            plan->d_hseg_check_owner = reinterpret_cast<uint32_t *>(block + r_hc.at);
-            plan->d_hseg_recs = reinterpret_cast<pq::HsegRec *>(block + r_hr.at);
-            plan->d_hseg_counts = reinterpret_cast<uint32_t *>(block + r_hn.at);
-            plan->d_hseg_scans = reinterpret_cast<pq::HsegScan *>(block + r_hx.at);
+            for (int k = 0; k < 2; ++k) {
+                pq_plan::HsegDev &hd = plan->hs[k];
+                hd.d_pages = reinterpret_cast<pq::HsegPage *>(block + r_hp[k].at);
+                hd.d_seg_owner = reinterpret_cast<uint32_t *>(block + r_hs[k].at);
+                hd.d_check_owner = reinterpret_cast<uint32_t *>(block + r_hc[k].at);
+                hd.d_recs = reinterpret_cast<pq::HsegRec *>(block + r_hr[k].at);
+                hd.d_counts = reinterpret_cast<uint32_t *>(block + r_hn[k].at);
+                hd.d_scans = reinterpret_cast<pq::HsegScan *>(block + r_hx[k].at);
+                put(r_hp[k], hsh[k].pages.data());
+                put(r_hs[k], hsh[k].seg_owner.data());
+                put(r_hc[k], hsh[k].check_owner.data());
+            }
             plan->d_lowered = reinterpret_cast<uint32_t *>(block + r_low.at);
-            put(r_hp, hseg_pages.data());
-            put(r_hs, hseg_seg_owner.data());
-            put(r_hc, hseg_check_owner.data());
             put(r_low, lowered.data());
+            plan->d_npages = reinterpret_cast<pq::NestedPage *>(block + r_np.at);
+            put(r_np, npages.data());
+            if (keep_table) {
+                plan->d_descs0 = reinterpret_cast<pq_page_desc *>(block + r_descs0.at);
+                put(r_descs0, descs.data());
+            }
             if (n_sets > 1) {
                 plan->d_set_of = reinterpret_cast<uint32_t *>(block + r_set.at);
-                plan->d_descs0 = reinterpret_cast<pq_page_desc *>(block + r_descs0.at);
                 plan->d_deltas = reinterpret_cast<uint64_t *>(block + r_deltas.at);
                 put(r_set, set_of.data());
-                put(r_descs0, descs.data());
             }
             e = hipMemcpyAsync(block, h, img_bytes, hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess) e = hipEventRecord(ctx->host_img_done[slot], ctx->stream);
@@ -778,7 +872,7 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
             plan->d_descs = reinterpret_cast<pq_page_desc *>(block);  // for pq_plan_destroy
         }
         // nothing waits here: the tables are on their way on the stream the plan runs on
-        if (e == hipSuccess) e = hipMemsetAsync(plan->d_results, 0xff, n_pages * sizeof(pq_page_result), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(plan->d_results, 0xff, n_total * sizeof(pq_page_result), ctx->stream);
         if (e == hipSuccess && n_sets > 1) {
             e = hipHostMalloc((void **)&plan->h_deltas, n_sets * 4 * sizeof(uint64_t), hipHostMallocDefault);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&plan->deltas_sent, hipEventDisableTiming);
@@ -841,13 +935,24 @@ static int plan_launch(pq_plan *plan, pq::PageBuffers buf)
 {
     pq_ctx *ctx = plan->ctx;
     const pq::WaveLaunch wl{ctx->hybrid_wave_min_pages};
-    PQ_HIP(ctx, pq::launch_seg_hybrid(ctx->stream, plan->d_descs, plan->d_hseg_pages, plan->n_hseg_pages,
-                                      plan->d_hseg_check_owner, plan->n_hseg_checks, plan->d_hseg_counts,
-                                      plan->d_hseg_seg_owner, plan->n_hseg_segs, plan->d_hseg_recs, plan->d_hseg_scans, buf,
-                                      plan->d_results, plan->dict_lds_bytes));
+    auto seg_hybrid = [&](const pq_plan::HsegDev &hd) {
+        return pq::launch_seg_hybrid(ctx->stream, plan->d_descs, hd.d_pages, hd.n_pages, hd.d_check_owner, hd.n_checks,
+                                     hd.d_counts, hd.d_seg_owner, hd.n_segs, hd.d_recs, hd.d_scans, buf, plan->d_results,
+                                     plan->dict_lds_bytes);
+    };
+    if (plan->n_split != 0) {
+        // large nested pages: where their three sections lie, then the level units; the values run
+        // below among everything else, once their counts are known
+        PQ_HIP(ctx, pq::launch_nested_split(ctx->stream, plan->d_descs, plan->d_npages, plan->n_split, buf));
+        PQ_HIP(ctx, seg_hybrid(plan->hs[1]));
+        PQ_HIP(ctx, pq::launch_stream_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[6], plan->count[6], buf,
+                                            plan->d_results, 0, wl, plan->hs[1].d_pages, plan->hs[1].n_pages));
+        PQ_HIP(ctx, pq::launch_nested_values(ctx->stream, plan->d_descs, plan->d_npages, plan->n_split, plan->d_results));
+    }
+    PQ_HIP(ctx, seg_hybrid(plan->hs[0]));
     PQ_HIP(ctx, pq::launch_stream_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[0], plan->count[0], buf,
-                                        plan->d_results, plan->dict_lds_bytes, wl, plan->d_hseg_pages,
-                                        plan->n_hseg_pages));
+                                        plan->d_results, plan->dict_lds_bytes, wl, plan->hs[0].d_pages,
+                                        plan->hs[0].n_pages));
     plan->epoch += 1;
     if (plan->epoch == 0) plan->epoch = 1; // 0 is what the flag words start as
     bool serial32 = false, serial64 = false;
@@ -878,6 +983,7 @@ static int plan_launch(pq_plan *plan, pq::PageBuffers buf)
     // pages of flat columns that ran as their value streams: the stream's result becomes the page's
     PQ_HIP(ctx, pq::launch_lowered_finish(ctx->stream, plan->d_descs, plan->d_lowered, plan->n_lowered, buf,
                                           plan->d_results, plan->lowered_levels));
+    PQ_HIP(ctx, pq::launch_nested_finish(ctx->stream, plan->d_descs, plan->d_npages, plan->n_split, plan->d_results));
     return PQ_OK;
 }
 
@@ -908,6 +1014,8 @@ int pq_plan_run(pq_plan *plan, const void *d_src, size_t src_bytes, void *d_valu
     PQ_HIP(ctx, hipSetDevice(ctx->device));
     pq::PageBuffers buf{(const uint8_t *)d_src, (uint8_t *)d_values, (uint8_t *)d_levels,
                         (const uint8_t *)d_dict};
+    if (plan->d_descs0)  // the last run rewrote descriptors: start from the table as created
+        PQ_HIP(ctx, pq::launch_rebase(ctx->stream, plan->d_descs0, nullptr, nullptr, (uint32_t)plan->n_total, plan->d_descs));
     return plan_launch(plan, buf);
 }
 
@@ -925,7 +1033,11 @@ int pq_plan_run_sets(pq_plan *plan, const pq_buffer_set *sets, size_t n_sets)
     PQ_HIP(ctx, hipSetDevice(ctx->device));
     pq::PageBuffers buf{(const uint8_t *)sets[0].d_src, (uint8_t *)sets[0].d_values, (uint8_t *)sets[0].d_levels,
                         (const uint8_t *)sets[0].d_dict};
-    if (n_sets == 1) return plan_launch(plan, buf);
+    if (n_sets == 1) {
+        if (plan->d_descs0)
+            PQ_HIP(ctx, pq::launch_rebase(ctx->stream, plan->d_descs0, nullptr, nullptr, (uint32_t)plan->n_total, plan->d_descs));
+        return plan_launch(plan, buf);
+    }
     // Offsets are added to the first set's pointers in 64-bit arithmetic, so a set that lies
     // anywhere else is reached by moving its descriptors' offsets by the distance between the two
     // buffers (modulo 2^64).  The run before may still be reading the staging words.
@@ -941,7 +1053,7 @@ int pq_plan_run_sets(pq_plan *plan, const pq_buffer_set *sets, size_t n_sets)
     PQ_HIP(ctx, hipMemcpyAsync(plan->d_deltas, plan->h_deltas, n_sets * 4 * sizeof(uint64_t), hipMemcpyHostToDevice,
                                ctx->stream));
     PQ_HIP(ctx, hipEventRecord(plan->deltas_sent, ctx->stream));
-    PQ_HIP(ctx, pq::launch_rebase(ctx->stream, plan->d_descs0, plan->d_set_of, plan->d_deltas, (uint32_t)plan->n,
+    PQ_HIP(ctx, pq::launch_rebase(ctx->stream, plan->d_descs0, plan->d_set_of, plan->d_deltas, (uint32_t)plan->n_total,
                                   plan->d_descs));
     return plan_launch(plan, buf);
 }

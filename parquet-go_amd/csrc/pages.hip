@@ -1063,6 +1063,10 @@ __global__ __launch_bounds__(256) void rebase_kernel(const pq_page_desc *__restr
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     pq_page_desc d = in[i];
+    if (deltas == nullptr) {
+        out[i] = d;
+        return;
+    }
     const uint64_t *w = deltas + 4u * (size_t)set_of[i];
     const bool page = d.kind == PQ_KIND_PAGE_V1 || d.kind == PQ_KIND_PAGE_V2;
     const uint32_t vk = page ? d.value_kind : d.kind;

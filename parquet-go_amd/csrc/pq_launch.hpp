@@ -65,8 +65,9 @@ hipError_t launch_delta_serial(hipStream_t s, const pq_page_desc *d_descs, const
 hipError_t launch_lowered_finish(hipStream_t s, const pq_page_desc *d_descs, const uint32_t *d_ids, uint32_t count,
                                  PageBuffers buf, pq_page_result *d_results, bool write_levels);
 
-// Plans over several buffer sets: d_out[i] = d_in[i] with its offsets moved by d_deltas[4 * d_set_of[i] ..]
-// (src, values, levels, dict).
+// d_out[i] = d_in[i]; plans over several buffer sets: with its offsets moved by d_deltas[4 * d_set_of[i] ..]
+// (src, values, levels, dict).  d_set_of / d_deltas null: a plain copy (plans that rewrite descriptors
+// on the device start every run from the table as created).
 hipError_t launch_rebase(hipStream_t s, const pq_page_desc *d_in, const uint32_t *d_set_of, const uint64_t *d_deltas,
                          uint32_t n, pq_page_desc *d_out);
 
@@ -162,6 +163,28 @@ hipError_t launch_seg_hybrid(hipStream_t s, const pq_page_desc *d_descs, HsegPag
                              const uint32_t *d_check_owner, uint32_t n_checks, uint32_t *d_counts,
                              const uint32_t *d_seg_owner, uint32_t n_segs, HsegRec *d_recs, HsegScan *d_scans,
                              PageBuffers buf, pq_page_result *d_results, uint32_t dict_lds_bytes);
+
+// ---- large nested pages as three units (nested.hip) ---------------------------------------------
+// The host fills the first nine fields; the rest is written on the device every run.
+struct NestedPage {
+    uint32_t desc;      // the page's own descriptor slot: its value unit
+    uint32_t rep_unit;  // descriptor slots of the two level units
+    uint32_t def_unit;
+    uint32_t version;   // 1 or 2
+    uint32_t rep_len, def_len;  // V2: the header's level byte lengths
+    uint32_t max_rep, max_def;
+    uint32_t n_values;  // the header's NumValues: level slots
+    int32_t early_status, early_stage;  // read() itself failed
+    int32_t lvl_status, lvl_stage;      // how the level decode of ReadValues ended
+    uint32_t not_null;
+    uint32_t pad[2];
+};
+static_assert(sizeof(NestedPage) == 64, "nested page records are 64 bytes");
+hipError_t launch_nested_split(hipStream_t s, pq_page_desc *d_descs, NestedPage *d_pages, uint32_t n_pages, PageBuffers buf);
+hipError_t launch_nested_values(hipStream_t s, pq_page_desc *d_descs, NestedPage *d_pages, uint32_t n_pages,
+                                const pq_page_result *d_results);
+hipError_t launch_nested_finish(hipStream_t s, const pq_page_desc *d_descs, const NestedPage *d_pages, uint32_t n_pages,
+                                pq_page_result *d_results);
 
 // Level post-processing (assemble.hip).  d_out: ceil(n / 8) * w bytes, 4-byte aligned.
 hipError_t launch_levels_pack(hipStream_t s, const int32_t *d_levels, uint64_t n, int w, uint8_t *d_out);
