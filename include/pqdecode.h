@@ -125,6 +125,13 @@ int pq_ctx_synchronize(pq_ctx *ctx);
 #define PQ_OPT_SEGMENT_BYTES 4
 /* PQ_OPT_CHUNK_SLOTS: pipeline slots of pq_decode_chunks, 1..8 (default 3). */
 #define PQ_OPT_CHUNK_SLOTS 5
+/* PQ_OPT_SEGMENT_SPIN_LIMIT (for tests): the waves that decode the segments of one delta page learn
+ * where their segment stands in the page from the waves in front of them, and wait for that while
+ * the same kernel runs.  The wait is bounded: after this many looks a wave gives the page up, and the
+ * page is decoded whole by the kernel behind.  Default 2^20 (never reached on MI355X, where
+ * workgroups start in the order of their index); 0 = a wave that would have to wait gives up at once,
+ * which is how the tests reach that path.  Results are the same either way. */
+#define PQ_OPT_SEGMENT_SPIN_LIMIT 6
 int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value);
 const char *pq_status_string(int status);
 const char *pq_last_error(pq_ctx *ctx); /* text of the last HIP failure on ctx */

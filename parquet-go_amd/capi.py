@@ -29,6 +29,7 @@ OPT_HYBRID_WAVE_MIN_PAGES = 2
 OPT_SEGMENT_MAX_PAGES = 3
 OPT_SEGMENT_BYTES = 4
 OPT_CHUNK_SLOTS = 5
+OPT_SEGMENT_SPIN_LIMIT = 6
 
 STAGE_NONE, STAGE_REP_INIT, STAGE_DEF_INIT, STAGE_VALUES_INIT, STAGE_REP, STAGE_DEF, STAGE_VALUES = range(7)
 

@@ -49,6 +49,7 @@ struct pq_ctx {
     // pinned host staging for callers whose memory is pageable
     struct ChunkSlot *slots = nullptr;
     int n_slots = 3;  // slots pq_decode_chunks uses (PQ_OPT_CHUNK_SLOTS)
+    uint32_t seg_spin_limit = pq::kSegSpinLimit;  // PQ_OPT_SEGMENT_SPIN_LIMIT
     // all copies to the device go through one stream and all copies back through another, so that
     // each direction's copies queue up behind one another without gaps
     hipStream_t chunk_in = nullptr, chunk_out = nullptr;
@@ -95,6 +96,7 @@ struct pq_plan {
     pq::SegPage *d_seg_pages[2] = {nullptr, nullptr};
     uint32_t *d_seg_owner[2] = {nullptr, nullptr};
     pq::SegRec *d_seg_recs[2] = {nullptr, nullptr};
+    pq::SegLook *d_seg_looks[2] = {nullptr, nullptr};
     // hybrid streams that may be decoded in segments: [0] the last hs[0].n_pages ids of group 0, [1] the
     // level units of split nested pages (group 6, all of them candidates)
     struct HsegDev {
@@ -204,6 +206,7 @@ uint32_t value_size(const pq_page_desc &d)
 // turns the stream's result into the page's (page-v1.go:80-116).  Pages that decode no value
 // (max_def != 0: the constant level 0 never equals it), empty pages and V2 pages whose level bytes
 // are not all there stay with the page kernels.
+constexpr uint64_t kSegValues = 8192;        // values a segment of a run-dense hybrid stream aims at
 constexpr uint32_t kNestedSplitMin = 65536;  // level slots from which a nested page is worth three units
 constexpr uint32_t kFlagLowered = 0x80000000u;  // internal: never set by callers (validate refuses it)
 
@@ -433,6 +436,10 @@ int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value)
         // a segment holds at least one block header (a 256-value block is at most 1038 bytes)
         if (value != 0 && (value < 2048 || value > (1ll << 24) || (value & 15) != 0)) return PQ_ERR_BAD_ARGUMENT;
         ctx->seg_bytes = (uint32_t)value;
+        return PQ_OK;
+    case PQ_OPT_SEGMENT_SPIN_LIMIT:
+        if (value < 0) return PQ_ERR_BAD_ARGUMENT;
+        ctx->seg_spin_limit = value > 0xffffffffll ? 0xffffffffu : (uint32_t)value;
         return PQ_OK;
     default: return PQ_ERR_BAD_ARGUMENT;
     }
@@ -703,11 +710,11 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
             return units ? level_bound[i - n_pages] : descs[i].src_len;
         };
         // A run-dense stream (levels, run-heavy keys) holds many values per byte, and the work of a
-        // segment goes by its values: such a page gets shorter segments, about 8192 values each.
+        // segment goes by its values: such a page gets shorter segments, about kSegValues values each.
         auto seg_len = [&](uint32_t i) -> uint64_t {
             const pq_page_desc &d = descs[i];
             if (ctx->seg_bytes != 0 || d.n_values == 0) return L;
-            const uint64_t by_values = (8192ull * stream_bytes(i) / d.n_values + 15u) & ~15ull;
+            const uint64_t by_values = (kSegValues * stream_bytes(i) / d.n_values + 15u) & ~15ull;
             return std::min<uint64_t>(L, std::max<uint64_t>(by_values, 1024u));
         };
         auto cut = [&](uint32_t i) {
@@ -791,6 +798,8 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
         const Region r_res = take(n_total * sizeof(pq_page_result));
         Region r_sr[2];
         for (int k = 0; k < 2; ++k) r_sr[k] = take(seg_owner[k].size() * sizeof(pq::SegRec));
+        Region r_sl[2];
+        for (int k = 0; k < 2; ++k) r_sl[k] = take(seg_owner[k].size() * sizeof(pq::SegLook));
         Region r_hr[2], r_hn[2], r_hx[2];
         for (int k = 0; k < 2; ++k) {
             r_hr[k] = take(hsh[k].seg_owner.size() * sizeof(pq::HsegRec));
@@ -838,6 +847,7 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
                 plan->d_seg_pages[k] = reinterpret_cast<pq::SegPage *>(block + r_sp[k].at);
                 plan->d_seg_owner[k] = reinterpret_cast<uint32_t *>(block + r_so[k].at);
                 plan->d_seg_recs[k] = reinterpret_cast<pq::SegRec *>(block + r_sr[k].at);
+                plan->d_seg_looks[k] = reinterpret_cast<pq::SegLook *>(block + r_sl[k].at);
                 put(r_sp[k], seg_pages[k].data());
                 put(r_so[k], seg_owner[k].data());
             }
@@ -959,8 +969,8 @@ static int plan_launch(pq_plan *plan, pq::PageBuffers buf)
     for (int k = 0; k < 2; ++k)  // the pages cut into segments first: they are the long ones
         PQ_HIP(ctx, pq::launch_seg_delta(ctx->stream, k ? 64 : 32, plan->d_descs, plan->d_seg_pages[k],
                                          plan->n_seg_pages[k], plan->d_seg_owner[k], plan->n_segs[k],
-                                         plan->d_seg_recs[k], buf, plan->d_results, plan->d_flags + 32 * k,
-                                         plan->epoch));
+                                         plan->d_seg_recs[k], plan->d_seg_looks[k], buf, plan->d_results,
+                                         plan->d_flags + 32 * k, plan->epoch, ctx->seg_spin_limit));
     PQ_HIP(ctx, pq::launch_delta_pages(ctx->stream, 32, plan->d_descs, plan->d_ids + plan->first[1],
                                        plan->count[1] - plan->n_seg_pages[0], plan->count[1], buf, plan->d_results,
                                        ctx->delta_wave_min_pages, plan->d_flags, plan->epoch, &serial32));

@@ -86,18 +86,20 @@ struct SegPage {
     uint32_t total;      // value count the stream declares
     uint32_t pos0;       // stream offset of the first block header
     uint64_t first;      // first value
+    uint32_t giveup;     // a wave's wait for the segments in front of it ran out: the page is decoded whole
+    uint32_t pad;
 };
-// One record per segment, written on the device.
+// One record per segment, written on the device: what pq_plan_segments shows.
 constexpr uint32_t kSegSkip = 0, kSegPart = 1, kSegTail = 2, kSegWhole = 3;
 struct SegRec {
-    // written by the scan (a guess until the link pass has proven it)
+    // what the segment's walk found (from the guess, or from the true start when the guess was elsewhere)
     uint32_t key;      // stream offset of the first block's width bytes (0xffffffff: none found)
     uint32_t exit;     // header of the first block of the next segment, reached by walking whole blocks
     uint32_t nblk;     // blocks walked
     uint32_t exit_key; // stream offset of the width bytes of the header at `exit`
     uint64_t sum;      // sum of the walked blocks' deltas, without the first block's minDelta (segment 0: with it)
     uint32_t exit_md;  // minDelta of the header at `exit`
-    // written by the link pass
+    // its place in the page
     uint32_t flags;    // kSeg*: what the decode does with the segment
     uint64_t value;    // the value at position p0
     uint32_t entry;    // stream offset of the first block's header
@@ -106,10 +108,20 @@ struct SegRec {
     uint32_t pad[3];
 };
 static_assert(sizeof(SegRec) == 64, "segment records are 64 bytes");
-// d_pages / d_owner (segment -> index into d_pages) / d_recs: n_pages, n_segs, n_segs entries.
+// One per segment: what the waves of one page show each other while the kernel runs (segdelta.hip
+// has the layout of the words).  A segment first shows a summary of its own walk (a0..a2), later
+// its place in the page (p0..p2: everything up to its end).
+struct SegLook {
+    uint64_t a0, a1, a2;
+    uint64_t p0, p1, p2;
+    uint64_t pad[2];
+};
+static_assert(sizeof(SegLook) == 64, "look-back records are 64 bytes");
+constexpr uint32_t kSegSpinLimit = 1u << 20;  // looks a wave takes at the segments in front of it before it gives up
+// d_pages / d_owner (segment -> index into d_pages) / d_recs / d_looks: n_pages, n_segs, n_segs, n_segs entries.
 hipError_t launch_seg_delta(hipStream_t s, int bits, const pq_page_desc *d_descs, SegPage *d_pages, uint32_t n_pages,
-                            const uint32_t *d_owner, uint32_t n_segs, SegRec *d_recs, PageBuffers buf,
-                            pq_page_result *d_results, uint32_t *d_flag, uint32_t epoch);
+                            const uint32_t *d_owner, uint32_t n_segs, SegRec *d_recs, SegLook *d_looks, PageBuffers buf,
+                            pq_page_result *d_results, uint32_t *d_flag, uint32_t epoch, uint32_t spin_limit);
 
 // ---- segmented hybrid streams (seghybrid.hip) ---------------------------------------------------
 // One record per hybrid stream (dictionary-index page, level stream, BOOLEAN RLE values, raw stream)

@@ -4,34 +4,38 @@
 // sum of everything in front).
 //
 // A page of the tiled layouts (blocks of 128 values / 4 miniblocks, or 256 / 4) is cut by BYTES
-// into segments of seg_bytes.  Four launches:
+// into segments of seg_bytes.  Two launches and a third of one lane per page:
 //   1. seg_header_kernel  one lane per page: the stream header (block size, miniblock count,
 //                         value count, first value).
-//   2. seg_scan_kernel    one wave per segment: finds the first block at or behind the segment's
-//                         first byte — by trying every byte offset in a block's length as a header
-//                         (one candidate per lane) and taking the first whose own fields and whose
-//                         successor's are well formed — then walks whole blocks from there to the
-//                         first header in the next segment, adding up their deltas.  The choice is
-//                         a guess: nothing is decoded from it.  What is guessed is where the
-//                         block's four width bytes are, not where its header starts: a minDelta
-//                         varint read from a byte too early (a byte of packed data with its top
-//                         bit set) or too late (inside the varint) parses just as well, so the
-//                         block's minDelta is left out of the sum and comes from the segment in
-//                         front, which reaches the header along the chain.
-//   3. seg_link_kernel    one wave per page: segment 0 starts at the true first header; segment
-//                         s + 1 is proven iff segment s is and its walk ended on a header whose
-//                         width bytes are where segment s + 1 guessed them (and that block still
-//                         has a value the caller wants).  Proven segments get their true header,
-//                         their first value's position and the value itself (prefix sums of block
-//                         counts and delta sums).  Where a guess was wrong the wave walks that
-//                         segment again itself, from where the chain says it starts, and goes on
-//                         (a few times per page; beyond that the rest of the page is left to the
-//                         last proven segment).
-//   4. seg_decode_kernel  one wave per proven segment decodes up to the next proven segment with
-//                         the page decoder's own tile loop; the last proven one runs to the end of
-//                         the page through the checked path, so the tail rules, the status and the
-//                         consumed bytes are those of the whole-page decode.  Everything behind
-//                         the first unproven segment is therefore decoded serially, as before.
+//   2. seg_fused_kernel   one wave per segment, in three steps.
+//      scan      finds the first block at or behind the segment's first byte — by trying every
+//                byte offset in a block's length as a header (one candidate per lane) and taking
+//                the first whose own fields and whose successor's are well formed — then walks
+//                whole blocks from there to the first header in the next segment, adding up their
+//                deltas.  The choice is a guess.  What is guessed is where the block's four width
+//                bytes are, not where its header starts: a minDelta varint read from a byte too
+//                early (a byte of packed data with its top bit set) or too late (inside the
+//                varint) parses just as well, so the block's minDelta is left out of the sum and
+//                comes from the segment in front, which reaches the header along the chain.
+//      look-back the wave shows what it found (its summary) and looks at the segments in front
+//                of it, 64 at a time: summaries whose guesses fit the walks in front of them, back
+//                to the nearest segment that already knows its place in the chain, add up to the
+//                number of blocks and the sum of deltas in front of this segment, and say where
+//                its first block really starts.  Segment 0 starts at the true first header and
+//                knows its place at once.  A wave whose guess was elsewhere walks its segment
+//                again from the true start; the segments behind it wait for that, and only for
+//                that.  Then it shows its own place (blocks and sum up to its end, the header its
+//                walk ended on), which ends the look-back of the waves behind it.  Workgroups start
+//                in the order of their index, so a wave only ever waits for waves that are running
+//                or done; the wait is bounded all the same, and a wave that runs out of patience
+//                leaves its page to the whole-page decoder (seg_post_kernel marks it).
+//      decode    the segment's blocks, with the page decoder's own tile loop, up to the next
+//                segment's first header.  The segment whose walk ended on anything but a plain
+//                block header, or which holds the last value the caller wants, runs to the end of
+//                the page through the checked path, so the tail rules, the status and the consumed
+//                bytes are those of the whole-page decode; the segments behind it do nothing.
+//   3. seg_post_kernel    one lane per page: hands a page some wave gave up on to the sweep
+//                         kernel behind (never seen to happen; the exit every wait must have).
 // A page whose header is unusual in any way is decoded whole by its segment 0.
 #include "delta_wave.hpp"
 #include "pq_launch.hpp"
@@ -45,9 +49,10 @@ constexpr uint32_t kSegNone = 0xffffffffu;
 template <typename UT>
 __global__ __launch_bounds__(kWave) void seg_header_kernel(const pq_page_desc *__restrict__ descs,
                                                            SegPage *__restrict__ pages, uint32_t n_pages,
-                                                           PageBuffers buf)
+                                                           PageBuffers buf, uint4 *__restrict__ looks, uint32_t n_look16)
 {
     const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+    if (i < n_look16) looks[i] = make_uint4(0u, 0u, 0u, 0u);  // nothing shown yet (16 bytes a lane)
     if (i >= n_pages) return;
     SegPage pg = pages[i];
     const pq_page_desc d = descs[pg.desc];
@@ -76,6 +81,7 @@ __global__ __launch_bounds__(kWave) void seg_header_kernel(const pq_page_desc *_
     pg.total = (uint32_t)total;
     pg.pos0 = (uint32_t)pos;
     pg.first = (uint64_t)f;
+    pg.giveup = 0;
     pages[i] = pg;
 }
 
@@ -89,17 +95,15 @@ struct SegCand {
     uint32_t next;  // window offset of the header behind this block
 };
 
-// What a scan leaves in a segment's record (the link fields are written by seg_link_kernel).
-__device__ __forceinline__ void seg_store(SegRec *rec, uint32_t key, uint32_t exit_off, uint32_t nblk, uint32_t exit_key,
-                                          uint64_t sum, uint32_t exit_md)
-{
-    rec->key = key;
-    rec->exit = exit_off;
-    rec->nblk = nblk;
-    rec->exit_key = exit_key;
-    rec->sum = sum;
-    rec->exit_md = exit_md;
-}
+// What a scan finds (the same in every lane).
+struct SegScan {
+    uint32_t key;       // stream offset of the first block's width bytes (kSegNone: none found)
+    uint32_t exit_off;  // header of the next segment's first block, reached by walking whole blocks (kSegNone: not reached)
+    uint32_t nblk;      // blocks walked
+    uint32_t exit_key;  // width bytes of the header at exit_off
+    uint64_t sum;       // sum of the walked deltas, without the first block's minDelta (segment 0: with it)
+    uint32_t exit_md;   // minDelta of the header at exit_off
+};
 
 template <uint32_t LG>
 __device__ __forceinline__ SegCand seg_parse(const uint32_t *lds, uint32_t wo, uint32_t lim)
@@ -129,8 +133,8 @@ __device__ __forceinline__ SegCand seg_parse(const uint32_t *lds, uint32_t wo, u
 
 // forced != kSegNone: no guess, the first block's width bytes are known to be at `forced`.
 template <uint32_t LG>
-__device__ __forceinline__ void seg_scan(uint32_t *lds, const uint8_t *S, int64_t len, uint32_t s, uint32_t seg_bytes,
-                                         uint32_t pos0, SegRec *rec, int lane, uint32_t forced = kSegNone)
+__device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int64_t len, uint32_t s, uint32_t seg_bytes,
+                                            uint32_t pos0, int lane, uint32_t forced = kSegNone)
 {
     constexpr uint32_t kBlockMax = LG == 5u ? 544u : 1040u;  // >= the longest block, a multiple of 16
     const int64_t lo = (int64_t)s * seg_bytes, hi = lo + seg_bytes;
@@ -171,10 +175,7 @@ __device__ __forceinline__ void seg_scan(uint32_t *lds, const uint8_t *S, int64_
         }
     }
     key = uni(key);
-    if (key == kSegNone) {
-        if (lane == 0) seg_store(rec, kSegNone, kSegNone, 0u, kSegNone, 0ull, 0u);
-        return;
-    }
+    if (key == kSegNone) return SegScan{kSegNone, kSegNone, 0u, kSegNone, 0ull, 0u};
 
     // whole blocks from there to the first block whose width bytes are at or behind `hi` (a
     // segment owns the blocks whose width bytes start in it).  The walk starts one byte in
@@ -296,219 +297,329 @@ __device__ __forceinline__ void seg_scan(uint32_t *lds, const uint8_t *S, int64_
         }
     }
     const uint64_t total = wave_last_u64(wave_scan_u64(acc));
-    if (lane == 0) seg_store(rec, key, exit_off, nblk, exit_key, total, exit_md);
+    return SegScan{key, uni(exit_off), uni(nblk), uni(exit_key), total, uni(exit_md)};
 }
 
-__global__ __launch_bounds__(kWG) void seg_scan_kernel(const pq_page_desc *__restrict__ descs,
-                                                       const SegPage *__restrict__ pages,
-                                                       const uint32_t *__restrict__ owner, uint32_t n_segs,
-                                                       SegRec *__restrict__ recs, PageBuffers buf)
+// ---- what segments show each other ------------------------------------------------------------
+// Six 64-bit words per segment, all zero when the kernel starts (seg_header_kernel clears them).
+// Bit 63 of a word says that it has been written; a record counts once all three of its words
+// show that bit.  Words are stored and loaded with relaxed agent-scope atomics and nothing else:
+// no fence, so no cache is written back or thrown away while the decode's output streams through.
+//   summary  a0: key | blocks walked << 32 | bit 63 of the sum << 56
+//            a1: header the walk ended on | bytes of its minDelta varint << 32 | its minDelta (28 bits) << 35
+//            a2: bits 0..62 of the sum
+//   place    p0: as a1, for the walk that counts (0xffffffff: the page ends with this segment or one
+//                in front; with varint bytes = 7: a wait ran out)
+//            p1: blocks up to there | bit 63 of the carry << 32
+//            p2: bits 0..62 of the carry (first value + every delta up to there)
+// A minDelta that is walked over has at most four varint bytes, so 28 bits hold it.
+constexpr uint64_t kLookBit = 1ull << 63;
+constexpr uint32_t kLookNone = 0, kLookSummary = 1, kLookPlace = 2, kLookGaveUp = 3;
+
+__device__ __forceinline__ uint64_t look_ld(const uint64_t *p)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t window[kWG / kWave][kDwChunk / 4 + 4];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t g = blockIdx.x * (kWG / kWave) + (uint32_t)wave;
-    if (g >= n_segs) return;
-    const SegPage pg = pages[owner[g]];
-    const uint32_t s = g - pg.seg_first;
-    if (pg.whole) {
-        if (lane == 0) seg_store(recs + g, kSegNone, kSegNone, 0u, kSegNone, 0ull, 0u);
-        return;
-    }
-    const pq_page_desc d = descs[pg.desc];
-    const uint8_t *S = buf.src + d.src_off;
-    if (pg.lg == 5u)
-        seg_scan<5>(window[wave], S, (int64_t)d.src_len, s, pg.seg_bytes, pg.pos0, recs + g, lane);
-    else
-        seg_scan<6>(window[wave], S, (int64_t)d.src_len, s, pg.seg_bytes, pg.pos0, recs + g, lane);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void look_st(uint64_t *p, uint64_t v)
+{
+    __hip_atomic_store(p, v | kLookBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t look_exit_word(uint32_t exit_off, uint32_t exit_key, uint32_t exit_md)
+{
+    if (exit_off == kSegNone) return (uint64_t)kSegNone;
+    return (uint64_t)exit_off | ((uint64_t)((exit_key - exit_off) & 7u) << 32) | ((uint64_t)(exit_md & 0x0fffffffu) << 35);
+}
+__device__ __forceinline__ void look_exit_fields(uint64_t w, uint32_t &exit_off, uint32_t &exit_key, uint32_t &exit_md)
+{
+    exit_off = (uint32_t)w;
+    exit_key = exit_off == kSegNone ? kSegNone : exit_off + ((uint32_t)(w >> 32) & 7u);
+    exit_md = (uint32_t)((int32_t)((uint32_t)(w >> 35) << 4) >> 4);
 }
 
-// ---- 3. proofs and prefix sums -----------------------------------------------------------------
-
-constexpr uint32_t kSegRepairs = 8;  // wrong guesses per page the link pass walks again itself
-
-__global__ __launch_bounds__(kWG) void seg_link_kernel(const pq_page_desc *__restrict__ descs,
-                                                       const SegPage *__restrict__ pages, uint32_t n_pages,
-                                                       SegRec *__restrict__ recs, PageBuffers buf)
+// Called by lane 0.
+__device__ __forceinline__ void look_show_summary(SegLook *r, const SegScan &a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t window[kWG / kWave][kDwChunk / 4 + 4];
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t wave = uni(threadIdx.x >> 6);
-    const uint32_t pi = blockIdx.x * (kWG / kWave) + wave;
-    if (pi >= n_pages) return;
-    const SegPage pg = pages[pi];
-    SegRec *R = recs + pg.seg_first;
-    const uint32_t ns = pg.n_segs;
-    if (pg.whole) {
-        for (uint32_t s = lane; s < ns; s += kWave) R[s].flags = s == 0u ? kSegWhole : kSegSkip;
-        return;
-    }
-    const pq_page_desc d = descs[pg.desc];
-    const uint8_t *S = buf.src + d.src_off;
-    const uint32_t need = min(d.n_values, pg.total);
-    const uint64_t V = 128ull << (pg.lg - 5u);
-    // K = number of proven segments (a prefix of the page's segments, at least segment 0)
-    uint32_t K = ns, repairs = 0;
-    uint64_t blocks_before = 0, carry = pg.first;
-    uint32_t prev_exit = kSegNone, prev_key = kSegNone, prev_md = 0;
-    uint32_t base = 0;
-    while (base < ns) {
-        const uint32_t s = base + lane;
-        const bool valid = s < ns;
-        uint32_t key = kSegNone, exit_off = kSegNone, nb = 0, exit_key = kSegNone, exit_md = 0;
-        uint64_t rsum = 0;
-        if (valid) {
-            const SegRec &r = R[s];
-            key = r.key;
-            exit_off = r.exit;
-            nb = r.nblk;
-            exit_key = r.exit_key;
-            exit_md = r.exit_md;
-            rsum = r.sum;
-        }
-        uint32_t b_exit = (uint32_t)__shfl_up((int)exit_off, 1);
-        uint32_t b_key = (uint32_t)__shfl_up((int)exit_key, 1);
-        uint32_t b_md = (uint32_t)__shfl_up((int)exit_md, 1);
-        if (lane == 0) {
-            b_exit = prev_exit;
-            b_key = prev_key;
-            b_md = prev_md;
-        }
-        const bool link = s == 0u || (key != kSegNone && b_key != kSegNone && b_key == key);
-        // the first block's minDelta, which the guess could not know
-        const uint64_t sum = valid ? rsum + (s == 0u ? 0ull : V * (uint64_t)(int64_t)(int32_t)b_md) : 0ull;
-        const uint32_t incl_b = wave_scan_u32(nb);
-        const uint64_t incl_s = wave_scan_u64(sum);
-        const uint64_t b_s = blocks_before + incl_b - nb;
-        const uint64_t carry_s = carry + incl_s - sum;
-        const bool wanted = V * b_s < (uint64_t)need;  // the segment's first value is one the caller pulls
-        const uint64_t bad = __builtin_amdgcn_ballot_w64(valid && !(link && wanted));
-        const uint32_t first_bad = bad != 0ull ? (uint32_t)__builtin_ctzll(bad) : (uint32_t)kWave;
-        if (bad != 0ull) {
-            // a wrong guess (the chain in front says where the segment starts, it still has values
-            // the caller wants, and the guess was elsewhere): walk the segment again from there
-            const uint32_t want_key = (uint32_t)__builtin_amdgcn_readlane((int)b_key, (int)first_bad);
-            const bool still = __builtin_amdgcn_readlane((int)(wanted ? 1u : 0u), (int)first_bad) != 0;
-            if (still && want_key != kSegNone && repairs < kSegRepairs) {
-                repairs += 1u;
-                const uint32_t sk = base + first_bad;
-                if (pg.lg == 5u)
-                    seg_scan<5>(window[wave], S, (int64_t)d.src_len, sk, pg.seg_bytes, pg.pos0, R + sk, (int)lane, want_key);
-                else
-                    seg_scan<6>(window[wave], S, (int64_t)d.src_len, sk, pg.seg_bytes, pg.pos0, R + sk, (int)lane, want_key);
-                __threadfence();  // lane 0 wrote the record; every lane reads it next
-                continue;         // the same 64 segments once more
+    look_st(&r->a0, (uint64_t)a.key | ((uint64_t)a.nblk << 32) | ((a.sum >> 63) << 56));
+    look_st(&r->a1, look_exit_word(a.exit_off, a.exit_key, a.exit_md));
+    look_st(&r->a2, a.sum & ~kLookBit);
+}
+// exit_off == kSegNone: the segments behind this one have nothing to do.
+__device__ __forceinline__ void look_show_place(SegLook *r, uint64_t blocks, uint64_t carry, uint32_t exit_off,
+                                                uint32_t exit_key, uint32_t exit_md)
+{
+    look_st(&r->p0, look_exit_word(exit_off, exit_key, exit_md));
+    look_st(&r->p1, (blocks & 0xffffffffull) | ((carry >> 63) << 32));
+    look_st(&r->p2, carry & ~kLookBit);
+}
+__device__ __forceinline__ void look_show_gave_up(SegLook *r)
+{
+    look_st(&r->p0, (uint64_t)kSegNone | (7ull << 32));
+    look_st(&r->p1, 0ull);
+    look_st(&r->p2, 0ull);
+}
+
+__device__ __forceinline__ uint64_t seg_readlane_u64(uint64_t x, uint32_t l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, (int)l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), (int)l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// What enters segment s (the same in every lane).
+constexpr uint32_t kInOk = 0, kInDead = 1, kInGaveUp = 2;
+struct SegIn {
+    uint32_t status;    // kInDead: a segment in front decodes to the end of the page; kInGaveUp: a wait ran out
+    uint32_t entry;     // stream offset of the header of the segment's first block
+    uint32_t want_key;  // ... of that block's width bytes
+    uint32_t md;        // that block's minDelta
+    uint64_t blocks;    // blocks in front of the segment
+    uint64_t carry;     // first value + every delta in front of the segment
+};
+
+// Called by a whole wave, s > 0.  L: the page's records.  Lane i looks at segment j - i.  A window
+// ends at the nearest segment that shows its place; the segments between it and s must show
+// summaries whose first block is where the walk in front of them ended (a summary that does not
+// fit is a wrong guess: its wave will walk again and show its place, which is waited for).  With
+// no place among 64 segments, 63 summaries are added up and the window moves on by 63 (the last
+// one is looked at again, next to the segment in front of it).
+__device__ __forceinline__ SegIn seg_look_back(const SegLook *L, uint32_t s, int lane, uint64_t V, uint32_t spin_limit)
+{
+    SegIn in{kInGaveUp, 0u, 0u, 0u, 0ull, 0ull};
+    uint64_t acc_blocks = 0, acc_sum = 0;
+    bool first_window = true;
+    int64_t j = (int64_t)s - 1;
+    uint32_t spins = 0;
+    while (true) {
+        const int64_t idx = j - lane;
+        uint32_t st = kLookNone, key = kSegNone, nblk = 0, exit_off = kSegNone, exit_key = kSegNone, md = 0, alive = 0;
+        uint64_t sum = 0, blocks = 0, carry = 0;
+        // few lanes at first: every look is a memory transaction per lane that no cache serves
+        uint32_t width = first_window ? 8u : (uint32_t)kWave;
+        uint64_t known;
+        uint32_t fp;
+        while (true) {
+            if (idx >= 0 && (uint32_t)lane < width && st < kLookPlace) {
+                const SegLook *r = L + idx;
+                const uint64_t p0 = look_ld(&r->p0);
+                if ((p0 & kLookBit) != 0ull) {
+                    const uint64_t p1 = look_ld(&r->p1), p2 = look_ld(&r->p2);
+                    if ((p1 & p2 & kLookBit) != 0ull) {
+                        look_exit_fields(p0, exit_off, exit_key, md);
+                        blocks = p1 & 0xffffffffull;
+                        carry = (p2 & ~kLookBit) | ((p1 >> 32) << 63);
+                        alive = exit_off != kSegNone ? 1u : 0u;
+                        st = exit_off == kSegNone && ((uint32_t)(p0 >> 32) & 7u) == 7u ? kLookGaveUp : kLookPlace;
+                    }
+                } else if (st == kLookNone) {
+                    const uint64_t a0 = look_ld(&r->a0), a1 = look_ld(&r->a1), a2 = look_ld(&r->a2);
+                    if ((a0 & a1 & a2 & kLookBit) != 0ull) {
+                        key = (uint32_t)a0;
+                        nblk = (uint32_t)(a0 >> 32) & 0xffffffu;
+                        look_exit_fields(a1, exit_off, exit_key, md);
+                        sum = (a2 & ~kLookBit) | (((a0 >> 56) & 1ull) << 63);
+                        st = kLookSummary;
+                    }
+                }
             }
+            known = __builtin_amdgcn_ballot_w64(st >= kLookPlace);
+            fp = known != 0ull ? (uint32_t)__builtin_ctzll(known) : (uint32_t)kWave;
+            if (known != 0ull) {
+                if ((uint32_t)__builtin_amdgcn_readlane((int)st, (int)fp) == kLookGaveUp) return in;
+                if (__builtin_amdgcn_readlane((int)alive, (int)fp) == 0) {
+                    in.status = kInDead;
+                    return in;
+                }
+            }
+            // the segment in front of this lane's is the next lane's
+            const uint32_t f_st = (uint32_t)__shfl_down((int)st, 1), f_exit_key = (uint32_t)__shfl_down((int)exit_key, 1);
+            const bool fits = st == kLookSummary && key != kSegNone && exit_key != kSegNone && lane < kWave - 1 &&
+                              (f_st == kLookSummary || f_st == kLookPlace) && f_exit_key == key;
+            bool ok;
+            if (known != 0ull)
+                ok = (uint32_t)lane >= fp || fits;
+            else
+                ok = (uint32_t)lane >= width || ((uint32_t)lane == width - 1u ? st == kLookSummary : fits);
+            const uint64_t waiting = __builtin_amdgcn_ballot_w64(!ok);
+            if (waiting == 0ull) {
+                if (known != 0ull || width == (uint32_t)kWave) break;
+                width = kWave;  // the near ones all fit and none knows its place
+                continue;
+            }
+            if (spins >= spin_limit) return in;
+            spins += 1u;
+            __builtin_amdgcn_s_sleep(2);
         }
-        if (valid && lane < first_bad) {
-            R[s].entry = s == 0u ? pg.pos0 : b_exit;  // the header itself, as the chain reached it
-            R[s].p0 = (uint32_t)(V * b_s);
-            R[s].value = carry_s;
+        const uint32_t cnt = known != 0ull ? fp : (uint32_t)kWave - 1u;
+        const bool mine = (uint32_t)lane < cnt;
+        const uint32_t f_md = (uint32_t)__shfl_down((int)md, 1);  // the first block's minDelta: where the walk in front ended
+        const uint64_t my_sum = mine ? sum + (nblk != 0u ? V * (uint64_t)(int64_t)(int32_t)f_md : 0ull) : 0ull;
+        acc_blocks += wave_sum_u32(mine ? nblk : 0u);
+        acc_sum += wave_last_u64(wave_scan_u64(my_sum));
+        if (first_window) {
+            in.entry = (uint32_t)__builtin_amdgcn_readlane((int)exit_off, 0);
+            in.want_key = (uint32_t)__builtin_amdgcn_readlane((int)exit_key, 0);
+            in.md = (uint32_t)__builtin_amdgcn_readlane((int)md, 0);
+            first_window = false;
         }
-        if (bad != 0ull) {
-            K = base + first_bad;
-            break;
+        if (known != 0ull) {
+            in.blocks = seg_readlane_u64(blocks, fp) + acc_blocks;
+            in.carry = seg_readlane_u64(carry, fp) + acc_sum;
+            in.status = kInOk;
+            return in;
         }
-        blocks_before += wave_last_u32(incl_b);
-        carry += wave_last_u64(incl_s);
-        prev_exit = (uint32_t)__builtin_amdgcn_readlane((int)exit_off, 63);
-        prev_key = (uint32_t)__builtin_amdgcn_readlane((int)exit_key, 63);
-        prev_md = (uint32_t)__builtin_amdgcn_readlane((int)exit_md, 63);
-        base += kWave;
-    }
-    K = uni(K);
-    for (uint32_t s = lane; s < ns; s += kWave) {
-        uint32_t flags = kSegSkip, stop = kSegNone;
-        if (s + 1u < K) {
-            flags = kSegPart;
-            stop = R[s].exit;  // the next proven segment's header
-        } else if (s + 1u == K) {
-            flags = kSegTail;
-        }
-        R[s].flags = flags;
-        R[s].stop = stop;
+        j -= kWave - 1;
     }
 }
 
-// ---- 4. decode ------------------------------------------------------------------------------------
+// ---- 2. scan, look back, decode --------------------------------------------------------------------
 
 template <typename UT>
-__global__ __launch_bounds__(kWG) void seg_decode_kernel(const pq_page_desc *__restrict__ descs,
-                                                         const SegPage *__restrict__ pages,
-                                                         const uint32_t *__restrict__ owner, uint32_t n_segs,
-                                                         const SegRec *__restrict__ recs, PageBuffers buf,
-                                                         pq_page_result *__restrict__ results, uint32_t *flag,
-                                                         uint32_t epoch)
+__global__ __launch_bounds__(kWG) void seg_fused_kernel(const pq_page_desc *__restrict__ descs, SegPage *pages,
+                                                        const uint32_t *__restrict__ owner, uint32_t n_segs,
+                                                        SegRec *__restrict__ recs, SegLook *looks, PageBuffers buf,
+                                                        pq_page_result *__restrict__ results, uint32_t *flag,
+                                                        uint32_t epoch, uint32_t spin_limit)
 {
     __shared__ __attribute__((aligned(16))) uint32_t window[kWG / kWave][kDwChunk / 4 + 4];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t g = blockIdx.x * (kWG / kWave) + (uint32_t)wave;
     if (g >= n_segs) return;
-    const SegRec rec = recs[g];
-    const uint32_t flags = uni(rec.flags);
-    if (flags == kSegSkip) return;
-    const SegPage pg = pages[owner[g]];
+    const uint32_t pi = owner[g];
+    const SegPage pg = pages[pi];
+    const uint32_t s = g - pg.seg_first;
     const pq_page_desc d = descs[pg.desc];
     const uint8_t *S = buf.src + d.src_off;
     const int64_t len = (int64_t)d.src_len;
     UT *dst = reinterpret_cast<UT *>(buf.values + d.dst_off);
     uint32_t *lds = window[wave];
+    SegRec *rec = recs + g;
+    SegRec out{};  // what pq_plan_segments shows of this segment
+    out.key = out.exit = out.exit_key = kSegNone;
+    out.flags = kSegSkip;
+    out.stop = kSegNone;
     WaveDeltaResult r;
-    if (flags == kSegWhole) {
+    bool tail = true;
+    if (pg.whole) {
+        if (s != 0u) {
+            if (lane == 0) *rec = out;
+            return;
+        }
+        out.flags = kSegWhole;
         r = delta_wave<UT>(lds, S, len, d.n_values, dst, lane);
     } else {
+        SegLook *L = looks + pg.seg_first;
+        const uint32_t need = min(d.n_values, pg.total);
+        const uint64_t V = 128ull << (pg.lg - 5u);
+        SegScan a = pg.lg == 5u ? seg_scan<5>(lds, S, len, s, pg.seg_bytes, pg.pos0, lane)
+                                : seg_scan<6>(lds, S, len, s, pg.seg_bytes, pg.pos0, lane);
+        uint64_t blocks = 0, carry = pg.first;
+        uint32_t entry = pg.pos0;
+        if (s != 0u) {
+            if (lane == 0) look_show_summary(L + s, a);
+            SegIn in = seg_look_back(L, s, lane, V, spin_limit);
+            // summaries say nothing of what the caller wants: a segment in front may hold the last value
+            if (in.status == kInOk && V * in.blocks >= (uint64_t)need) in.status = kInDead;
+            if (in.status != kInOk) {
+                if (lane == 0) {
+                    if (in.status == kInGaveUp) {
+                        look_show_gave_up(L + s);
+                        __hip_atomic_store(&pages[pi].giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        look_show_place(L + s, 0ull, 0ull, kSegNone, kSegNone, 0u);
+                    }
+                    out.key = a.key;
+                    *rec = out;
+                }
+                return;
+            }
+            if (a.key != in.want_key)  // the guess was elsewhere: once more, from where the chain says
+                a = pg.lg == 5u ? seg_scan<5>(lds, S, len, s, pg.seg_bytes, pg.pos0, lane, in.want_key)
+                                : seg_scan<6>(lds, S, len, s, pg.seg_bytes, pg.pos0, lane, in.want_key);
+            blocks = in.blocks;
+            carry = in.carry;
+            entry = in.entry;
+            a.sum += a.nblk != 0u ? V * (uint64_t)(int64_t)(int32_t)in.md : 0ull;
+        }
+        // the last one with a wave of its own: nothing to go on from, or nothing wanted behind it
+        tail = a.exit_key == kSegNone || s + 1u == pg.n_segs || V * (blocks + a.nblk) >= (uint64_t)need;
+        if (lane == 0) {
+            look_show_place(L + s, blocks + a.nblk, carry + a.sum, tail ? kSegNone : a.exit_off, a.exit_key, a.exit_md);
+            out.key = a.key;
+            out.exit = a.exit_off;
+            out.nblk = a.nblk;
+            out.exit_key = a.exit_key;
+            out.sum = a.sum;
+            out.exit_md = a.exit_md;
+            out.flags = tail ? kSegTail : kSegPart;
+            out.value = carry;
+            out.entry = entry;
+            out.p0 = (uint32_t)(V * blocks);
+            out.stop = tail ? kSegNone : a.exit_off;
+            *rec = out;
+        }
         const bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & (2 * sizeof(UT) - 1)) == 0;
-        const int64_t entry = (int64_t)uni(rec.entry);
-        const int64_t stop = flags == kSegPart ? (int64_t)uni(rec.stop) : -1;
-        const uint32_t p0 = uni(rec.p0);
-        const uint64_t first = ((uint64_t)uni((uint32_t)(rec.value >> 32)) << 32) | uni((uint32_t)rec.value);
+        const int64_t stop = tail ? -1 : (int64_t)a.exit_off;
         WavePrefetch pf;
-        const int64_t c0 = chunk_base(S, entry);
+        const int64_t c0 = chunk_base(S, (int64_t)entry);
+        wave_sync();  // the scan's last reads of the window are done
         wave_fetch(pf, S, c0, len, lane);
         wave_commit(lds, pf, lane);
         wave_sync();
         if (pg.lg == 5u)
-            r = delta_wave_tiles<UT, 5, false, true>(lds, S, len, d.n_values, dst, lane, pf, c0, entry, pg.total, first,
-                                                     vec_ok, nullptr, p0, stop);
+            r = delta_wave_tiles<UT, 5, false, true>(lds, S, len, d.n_values, dst, lane, pf, c0, (int64_t)entry, pg.total,
+                                                     carry, vec_ok, nullptr, (uint32_t)(V * blocks), stop);
         else
-            r = delta_wave_tiles<UT, 6, false, true>(lds, S, len, d.n_values, dst, lane, pf, c0, entry, pg.total, first,
-                                                     vec_ok, nullptr, p0, stop);
-        if (flags == kSegPart) return;  // the page's result comes from the wave that reaches its end
+            r = delta_wave_tiles<UT, 6, false, true>(lds, S, len, d.n_values, dst, lane, pf, c0, (int64_t)entry, pg.total,
+                                                     carry, vec_ok, nullptr, (uint32_t)(V * blocks), stop);
+        if (!tail) return;  // the page's result comes from the wave that reaches its end
     }
     if (lane == 0) {
-        pq_page_result out;
-        out.status = r.status;
-        out.stage = r.init_failed ? PQ_STAGE_VALUES_INIT : PQ_STAGE_NONE;  // Init failed, not DecodeValues
-        out.detail = 0;
-        out.n_decoded = r.n_decoded;
-        out.not_null = 0;
-        out.n_levels = 0;
-        out.consumed = r.consumed;
-        results[pg.desc] = out;
+        if (pg.whole) *rec = out;
+        pq_page_result res;
+        res.status = r.status;
+        res.stage = r.init_failed ? PQ_STAGE_VALUES_INIT : PQ_STAGE_NONE;  // Init failed, not DecodeValues
+        res.detail = 0;
+        res.n_decoded = r.n_decoded;
+        res.not_null = 0;
+        res.n_levels = 0;
+        res.consumed = r.consumed;
+        results[pg.desc] = res;
         if (r.status == kNeedGeneric) *flag = epoch;  // wakes the sweep kernel
     }
 }
 
+// ---- 3. pages a wave gave up on -----------------------------------------------------------------------
+
+__global__ __launch_bounds__(kWave) void seg_post_kernel(const SegPage *__restrict__ pages, uint32_t n_pages,
+                                                         pq_page_result *__restrict__ results, uint32_t *flag,
+                                                         uint32_t epoch)
+{
+    const uint32_t i = blockIdx.x * kWave + threadIdx.x;
+    if (i >= n_pages || pages[i].giveup == 0u) return;
+    results[pages[i].desc].status = kNeedGeneric;  // the sweep kernel decodes the page whole
+    *flag = epoch;
+}
+
 hipError_t launch_seg_delta(hipStream_t s, int bits, const pq_page_desc *d_descs, SegPage *d_pages, uint32_t n_pages,
-                            const uint32_t *d_owner, uint32_t n_segs, SegRec *d_recs, PageBuffers buf,
-                            pq_page_result *d_results, uint32_t *d_flag, uint32_t epoch)
+                            const uint32_t *d_owner, uint32_t n_segs, SegRec *d_recs, SegLook *d_looks, PageBuffers buf,
+                            pq_page_result *d_results, uint32_t *d_flag, uint32_t epoch, uint32_t spin_limit)
 {
     if (n_pages == 0 || n_segs == 0) return hipSuccess;
     const uint32_t per = kWG / kWave;
-    const dim3 gp((n_pages + kWave - 1) / kWave), gs((n_segs + per - 1) / per), gl((n_pages + per - 1) / per);
-    if (bits == 64)
-        hipLaunchKernelGGL(seg_header_kernel<uint64_t>, gp, dim3(kWave), 0, s, d_descs, d_pages, n_pages, buf);
-    else
-        hipLaunchKernelGGL(seg_header_kernel<uint32_t>, gp, dim3(kWave), 0, s, d_descs, d_pages, n_pages, buf);
-    hipLaunchKernelGGL(seg_scan_kernel, gs, dim3(kWG), 0, s, d_descs, d_pages, d_owner, n_segs, d_recs, buf);
-    hipLaunchKernelGGL(seg_link_kernel, gl, dim3(kWG), 0, s, d_descs, d_pages, n_pages, d_recs, buf);
-    if (bits == 64)
-        hipLaunchKernelGGL(seg_decode_kernel<uint64_t>, gs, dim3(kWG), 0, s, d_descs, d_pages, d_owner, n_segs, d_recs,
-                           buf, d_results, d_flag, epoch);
-    else
-        hipLaunchKernelGGL(seg_decode_kernel<uint32_t>, gs, dim3(kWG), 0, s, d_descs, d_pages, d_owner, n_segs, d_recs,
-                           buf, d_results, d_flag, epoch);
+    const uint32_t n_look16 = n_segs * (uint32_t)(sizeof(SegLook) / 16);
+    const dim3 gp((n_pages + kWave - 1) / kWave), gs((n_segs + per - 1) / per), gh((max(n_pages, n_look16) + kWave - 1) / kWave);
+    uint4 *looks16 = reinterpret_cast<uint4 *>(d_looks);
+    if (bits == 64) {
+        hipLaunchKernelGGL(seg_header_kernel<uint64_t>, gh, dim3(kWave), 0, s, d_descs, d_pages, n_pages, buf, looks16, n_look16);
+        hipLaunchKernelGGL(seg_fused_kernel<uint64_t>, gs, dim3(kWG), 0, s, d_descs, d_pages, d_owner, n_segs, d_recs, d_looks,
+                           buf, d_results, d_flag, epoch, spin_limit);
+    } else {
+        hipLaunchKernelGGL(seg_header_kernel<uint32_t>, gh, dim3(kWave), 0, s, d_descs, d_pages, n_pages, buf, looks16, n_look16);
+        hipLaunchKernelGGL(seg_fused_kernel<uint32_t>, gs, dim3(kWG), 0, s, d_descs, d_pages, d_owner, n_segs, d_recs, d_looks,
+                           buf, d_results, d_flag, epoch, spin_limit);
+    }
+    hipLaunchKernelGGL(seg_post_kernel, gp, dim3(kWave), 0, s, d_pages, n_pages, d_results, d_flag, epoch);
     return hipGetLastError();
 }
 

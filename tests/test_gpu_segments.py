@@ -164,6 +164,35 @@ def test_wrong_guesses_fall_back_to_the_chain(ctx, bits):
     _run(ctx, cases, bits, 8192, seed=5)
 
 
+@pytest.mark.parametrize("bits", [32, 64])
+def test_waves_that_run_out_of_patience_leave_the_page_to_the_whole_page_decoder(ctx, bits):
+    """A segment's wave learns its place in the page from the waves in front of it, and its wait for them is
+    bounded.  With the bound at 0 looks (PQ_OPT_SEGMENT_SPIN_LIMIT) every wave that would have to wait gives up at
+    once: such a page is marked and decoded whole by the kernel behind.  Values, counts, status and consumed bytes
+    are the oracle's all the same, for good pages, cut pages and pages whose guesses are wrong."""
+    rng = np.random.default_rng(900 + bits)
+    dt = np.int32 if bits == 32 else np.int64
+    cases = []
+    for n, wmax, block in ((300_000, 16, 128), (120_000, 7, 256), (60_000, 2, 128), (200_000, 24, 128)):
+        vals = _values(rng, n, wmax, dt)
+        stream = synth.delta_encode(vals, bits, block, 4)
+        cases.append(_case(bits, stream, n))
+        cases.append(_case(bits, stream, n // 3))
+        cut = int(stream.size * 0.77)
+        c = Case(cases[-1].kind, stream[:cut].copy(), n)
+        c.result_src_len = cut
+        cases.append(c)
+    stride = (np.arange(60000, dtype=np.int64) * 5 + 17).astype(dt)    # every offset looks like a header
+    cases.append(_case(bits, synth.delta_encode(stride, bits, 128, 4), stride.size))
+    try:
+        for limit in (0, 3):
+            ctx.set_option(K.OPT_SEGMENT_SPIN_LIMIT, limit)
+            _run(ctx, cases, bits, 2048, seed=21 + limit)
+            _run(ctx, cases, bits, 16384, seed=23 + limit)
+    finally:
+        ctx.set_option(K.OPT_SEGMENT_SPIN_LIMIT, 1 << 20)
+
+
 def _mixed_width_values(rng, n, dt):
     """Deltas whose miniblocks (32 values) differ in width, 0 and 32 bits included, under block
     minimums whose zig-zag varints take one to five bytes."""
