@@ -350,45 +350,75 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-    // ---- pass A: lengths -> offsets, and the first value DecodeValues fails at ----
+    // ---- one pass over batches of values: lengths -> offsets, the first value DecodeValues fails at,
+    // and the bytes ----
+    // Batches of up to 64 values (one per lane).  A batch's lengths are read once: its offsets (which
+    // take the place of the suffix lengths, one slot further on) and the checks of the reference's
+    // loop come from wave scans of them.  The batch is then put together in LDS: its suffix bytes
+    // are staged with 16-byte loads, every byte of a value finds its suffix there (or in the value
+    // in front of the batch, which the output window still holds), and whole 16-byte pieces of the
+    // output window go to memory.  The window is circular, indexed by the low bits of the output
+    // ADDRESS, so a 16-byte piece of memory is a 16-byte piece of LDS and nothing is ever moved.
     const uint32_t total = ls.total;
     const uint64_t avail = (uint64_t)len - init_consumed;  // suffix bytes
     const uint32_t m = min(n, total);
-    uint64_t scarry = 0, ocarry = 0;
-    uint32_t prev_carry = 0, done = 0;
+    const uint8_t *SUF = S + init_consumed;
+    uint8_t *obuf = reinterpret_cast<uint8_t *>(window);  // the lengths are done with the window
+    uint8_t *sbuf = obuf + kBaOutWin;
+    const uint32_t dlow = (uint32_t)reinterpret_cast<uintptr_t>(data);
+    const uint64_t below = (2ull << lane) - 1ull;
+    bool prev_in_lds = false;
+    uint64_t sc = 0;        // suffix bytes in front of this batch
+    uint64_t oc = 0;        // value bytes in front of this batch: its first value's offset
+    uint32_t prev_len = 0;  // length of the value in front of this batch
+    uint32_t o_prev = 0;    // its offset
+    uint32_t flushed = 0;   // data[0, flushed) is in memory; [flushed, batch start) waits in the window
+    uint32_t base = 0;
     int32_t status = PQ_OK;
-    auto load_word = [&](const uint32_t *base, uint32_t i) -> int32_t {
-        return i < m ? (int32_t)__hip_atomic_load(base + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+    res.consumed = init_consumed;
+    auto load_word = [&](const uint32_t *from, uint32_t i) -> int32_t {
+        return i < m ? (int32_t)__hip_atomic_load(from + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+    };
+    // The lengths of the 64 values from `b` on, when this batch took `took` of the 64 it looked at:
+    // those it left come over from the lanes that hold them (the offset stored behind the last
+    // value taken has overwritten the first of them in memory), the others are loaded.
+    auto next_lens = [&](uint32_t b, uint32_t took, int32_t have_s, int32_t have_p, int32_t &ns, int32_t &np) {
+        const uint32_t from = (uint32_t)lane + took;
+        const int32_t moved_s = __shfl(have_s, (int)(from & 63u)), moved_p = __shfl(have_p, (int)(from & 63u));
+        const bool fresh = from >= (uint32_t)kWave;
+        const int32_t ld_s = fresh ? load_word(area, b + (uint32_t)lane) : 0;
+        const int32_t ld_p = fresh ? load_word(P, b + (uint32_t)lane) : 0;
+        ns = fresh ? ld_s : moved_s;
+        np = fresh ? ld_p : moved_p;
     };
     int32_t cur_s = load_word(area, (uint32_t)lane), cur_p = load_word(P, (uint32_t)lane);
-    res.consumed = init_consumed;
-    for (uint32_t base = 0; base < m; base += kWave) {
-        // offsets[i + 1] takes the place of suffix length i + 1: load the next batch first (the prefix
-        // lengths with it: a load inside the batch that needs it left the wave waiting once per batch)
-        const int32_t next_s = load_word(area, base + kWave + (uint32_t)lane);
-        const int32_t next_p = load_word(P, base + kWave + (uint32_t)lane);
+    if (lane == 0) area[0] = 0;
+    bool stop = false;
+    while (base < m && !stop) {
         const uint32_t i = base + (uint32_t)lane;
-        const bool live = i < m;
-        const int32_t s = cur_s, p = cur_p;
-        const bool neg_s = live && s < 0;  // make([]byte, size) panics (:210)
-        const uint64_t sincl = scarry + wave_scan_u64(live && !neg_s ? (uint64_t)(uint32_t)s : 0ull);
-        const bool rd_fail = live && !neg_s && sincl > avail;                // io.ReadFull (:212)
-        const bool neg_cap = live && !neg_s && (int64_t)p + (int64_t)s < 0;  // make(.., 0, prefixLen + len(suffix)) (:326)
-        const uint32_t pz = p > 0 ? (uint32_t)p : 0u;
-        const uint32_t vlen = live && !neg_s && !neg_cap ? pz + (uint32_t)s : 0u;
-        const uint32_t up = (uint32_t)__shfl_up((int)vlen, 1);
-        const uint32_t prev_len = lane == 0 ? prev_carry : up;
-        const bool bad_p = live && (int64_t)prev_len < (int64_t)p;  // :328-336
+        const bool in_range = i < m;
+        const int32_t sl = cur_s, pl = cur_p;
+        // ---- the reference's loop, value by value (:318-343), for the whole batch at once ----
+        const bool neg_s = in_range && sl < 0;  // make([]byte, size) panics (:210)
+        // lengths below 2^24 (any real page): 64 of them add up in 32 bits, one scan instead of two and a carry count
+        const bool small = __builtin_amdgcn_ballot_w64(in_range && (((uint32_t)sl | (uint32_t)pl) >> 24) != 0u) == 0ull;
+        const uint64_t s_here = in_range && !neg_s ? (uint64_t)(uint32_t)sl : 0ull;
+        const uint64_t sincl = sc + (small ? (uint64_t)wave_scan_u32((uint32_t)s_here) : wave_scan_u64(s_here));
+        const bool rd_fail = in_range && !neg_s && sincl > avail;                  // io.ReadFull (:212)
+        const bool neg_cap = in_range && !neg_s && (int64_t)pl + (int64_t)sl < 0;  // make(.., 0, prefixLen + len(suffix)) (:326)
+        const uint32_t pz = pl > 0 ? (uint32_t)pl : 0u;
+        const uint32_t vlen_all = in_range && !neg_s && !neg_cap ? pz + (uint32_t)sl : 0u;
+        const uint32_t up = (uint32_t)__shfl_up((int)vlen_all, 1);
+        const uint32_t before_len = lane == 0 ? prev_len : up;
+        const bool bad_p = in_range && (int64_t)before_len < (int64_t)pl;  // :328-336
         const uint64_t fm = __builtin_amdgcn_ballot_w64(neg_s || rd_fail || neg_cap || bad_p);
-        const uint32_t ok_lanes = fm ? (uint32_t)__builtin_ctzll(fm) : (uint32_t)kWave;
-        const uint64_t oincl = ocarry + wave_scan_u64((uint64_t)vlen);
-        if (live && (uint32_t)lane < ok_lanes) area[i + 1] = (uint32_t)oincl;
+        const uint32_t good = fm ? (uint32_t)__builtin_ctzll(fm) : (uint32_t)kWave;  // values of the batch in front of the first failure
+        const uint64_t v_here = (uint32_t)lane < good ? (uint64_t)vlen_all : 0ull;
+        const uint64_t oincl = oc + (small ? (uint64_t)wave_scan_u32((uint32_t)v_here) : wave_scan_u64(v_here));
         if (fm != 0ull) {
-            const uint32_t f = ok_lanes;
-            const uint64_t s_before = f ? wave_readlane_u64(sincl, f - 1u) : scarry;
+            const uint32_t f = good;
+            const uint64_t s_before = f ? wave_readlane_u64(sincl, f - 1u) : sc;
             const uint64_t s_at = wave_readlane_u64(sincl, f);
-            ocarry = f ? wave_readlane_u64(oincl, f - 1u) : ocarry;
-            done = base + f;
             if ((__builtin_amdgcn_ballot_w64(neg_s) >> f) & 1ull) {
                 status = PQ_BYTE_ARRAY_NEGATIVE_LEN;
                 res.consumed = init_consumed + s_before;
@@ -402,76 +432,41 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
                 status = PQ_BYTE_ARRAY_INVALID_PREFIX;
                 res.consumed = init_consumed + s_at;
             }
+        }
+        const uint32_t n_in = min(min((uint32_t)kWave, m - base), good);  // values this batch may take
+        if (n_in == 0u) {
+            // the batch's first value fails; what the batch in front left in the window goes out
+            const uint32_t pend = (uint32_t)oc - flushed;  // < 16 bytes
+            if ((uint32_t)lane < pend) data[flushed + lane] = obuf[(dlow + flushed + (uint32_t)lane) & (kBaOutWin - 1u)];
             break;
         }
-        scarry = wave_last_u64(sincl);
-        ocarry = wave_last_u64(oincl);
-        prev_carry = (uint32_t)__builtin_amdgcn_readlane((int)vlen, 63);
-        done = min(base + (uint32_t)kWave, m);
-        cur_s = next_s;
-        cur_p = next_p;
-        res.consumed = init_consumed + scarry;
-    }
-    if (lane == 0) area[0] = 0;
-    if (ocarry > data_cap) {
-        res.status = PQ_ERR_OUT_OF_RANGE;
-        res.n_decoded = 0;
-        return res;
-    }
-    if (status == PQ_OK && n > total) status = PQ_EOF;  // next() past the last length (:205-207)
-    res.status = status;
-    res.n_decoded = status == PQ_BYTE_ARRAY_INVALID_PREFIX ? 0u : done;  // "return 0, err" (:330)
-    if (res.n_decoded == 0) return res;
-    done = res.n_decoded;
-
-    // ---- pass B: the bytes ----
-    // Batches of up to 64 values (one per lane) are put together in LDS: the batch's suffix bytes
-    // are staged with 16-byte loads, every byte of a value finds its suffix there (or in the value
-    // in front of the batch, which the output window still holds), and whole 16-byte pieces of the
-    // output window go to memory.  The window is circular, indexed by the low bits of the output
-    // ADDRESS, so a 16-byte piece of memory is a 16-byte piece of LDS and nothing is ever moved.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const uint8_t *SUF = S + init_consumed;
-    uint8_t *obuf = reinterpret_cast<uint8_t *>(window);  // the lengths are done with the window
-    uint8_t *sbuf = obuf + kBaOutWin;
-    const uint32_t dlow = (uint32_t)reinterpret_cast<uintptr_t>(data);
-    const uint64_t below = (2ull << lane) - 1ull;
-    bool prev_in_lds = false;
-    uint32_t sc = 0;       // suffix bytes in front of this batch
-    uint32_t o_prev = 0;   // offset of the value in front of this batch
-    uint32_t flushed = 0;  // data[0, flushed) is in memory; [flushed, batch start) waits in the window
-    uint32_t base = 0;
-    // lengths of the 64 values from b on; the next batch's are asked for while this one's suffix
-    // bytes are on their way
-    auto load_lens = [&](uint32_t b, uint32_t &a0, uint32_t &a1, int32_t &ap) {
-        const uint32_t i = b + (uint32_t)lane;
-        const bool in = i < done;
-        a0 = in ? __hip_atomic_load(area + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-        a1 = in ? __hip_atomic_load(area + i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
-        ap = in ? (int32_t)P[i] : 0;
-    };
-    uint32_t o0, o1;
-    int32_t pr;
-    load_lens(0, o0, o1, pr);
-    while (base < done) {
-        const bool in_range = base + (uint32_t)lane < done;
-        const uint32_t o_start = uni(o0);
+        // values that do not fit the caller's area: nothing is returned
+        const uint64_t o_last = wave_readlane_u64(oincl, n_in - 1u);
+        if (o_last > data_cap) {
+            res.status = PQ_ERR_OUT_OF_RANGE;
+            res.n_decoded = 0;
+            return res;
+        }
+        const uint32_t o1 = (uint32_t)oincl, o0 = o1 - ((uint32_t)lane < good ? vlen_all : 0u);
+        const bool usable = (uint32_t)lane < n_in;
+        const uint32_t o_start = (uint32_t)oc;
         const uint32_t ws = min(prev_in_lds ? o_prev : o_start, flushed);  // the window has to hold [ws, batch end)
-        const uint64_t fits = __builtin_amdgcn_ballot_w64(in_range && o1 - ws <= kBaOutWin);
+        const uint64_t fits = __builtin_amdgcn_ballot_w64(usable && o1 - ws <= kBaOutWin);
         const uint32_t nb = ~fits ? (uint32_t)__builtin_ctzll(~fits) : (uint32_t)kWave;
         if (nb == 0u || (base != 0u && !prev_in_lds)) {
             // a value the window cannot hold next to the one in front of it, or whose predecessor
             // the window does not hold: straight through memory
+            int32_t ns, np;
+            next_lens(base + 1u, 1u, cur_s, cur_p, ns, np);
             const uint32_t pend = o_start - flushed;  // < 16 bytes of the batch in front
             if ((uint32_t)lane < pend) data[flushed + lane] = obuf[(dlow + flushed + (uint32_t)lane) & (kBaOutWin - 1u)];
-            const uint32_t vl = uni(o1) - o_start;
-            const uint32_t pl = uni(pr > 0 ? (uint32_t)pr : 0u);
-            if (pl > 0u) {
+            const uint32_t vl = uni(vlen_all);
+            const uint32_t pfx = uni(pz);
+            if (pfx > 0u) {
                 workgroup_fence();  // the value in front has to be in memory
-                wave_copy_bytes(data + o_start, data + o_prev, pl, lane);
+                wave_copy_bytes(data + o_start, data + o_prev, pfx, lane);
             }
-            wave_copy_bytes(data + o_start + pl, SUF + sc, vl - pl, lane);
+            wave_copy_bytes(data + o_start + pfx, SUF + sc, vl - pfx, lane);
             workgroup_fence();
             prev_in_lds = vl <= kBaOutWin;
             if (prev_in_lds) {  // back into the window, for the batch behind it
@@ -479,19 +474,25 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
                     obuf[(dlow + o_start + j) & (kBaOutWin - 1u)] = data[o_start + j];
                 wave_sync();
             }
+            if (lane == 0) area[base + 1u] = o_start + vl;
             o_prev = o_start;
             flushed = o_start + vl;
-            sc += vl - pl;
+            prev_len = vl;
+            sc += vl - pfx;
+            oc += vl;
             base += 1u;
-            load_lens(base, o0, o1, pr);
+            res.consumed = fm != 0ull && good == 1u ? res.consumed : init_consumed + sc;
+            stop = fm != 0ull && good == 1u;
+            cur_s = ns;
+            cur_p = np;
             continue;
         }
         const bool live = (uint32_t)lane < nb;
-        const uint32_t p = live ? (pr > 0 ? (uint32_t)pr : 0u) : 0x7fffffffu;
-        const uint32_t vlen = live ? o1 - o0 : 0u;
-        const uint32_t s = live ? vlen - p : 0u;
-        const uint32_t sincl = wave_scan_u32(s);
-        const uint32_t stot = wave_last_u32(sincl);
+        const uint32_t p = live ? pz : 0x7fffffffu;
+        const uint32_t vlen = live ? vlen_all : 0u;
+        const uint32_t s = live ? vlen - pz : 0u;
+        const uint32_t sincl32 = (uint32_t)(sincl - sc);  // the lanes that are live added their suffix lengths above
+        const uint32_t stot = (uint32_t)__builtin_amdgcn_readlane((int)sincl32, (int)(nb - 1u));
         const uint32_t o_end = (uint32_t)__builtin_amdgcn_readlane((int)o1, (int)(nb - 1u));
 
         // the batch's suffix bytes: every 16-byte piece of the stream's buffer that holds one
@@ -505,9 +506,10 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
             const uint32_t q = (uint32_t)lane + kWave * u;
             if (q < spieces) sv[u] = s16[q];
         }
-        uint32_t n0, n1;
-        int32_t np;
-        load_lens(base + nb, n0, n1, np);
+        // the next batch's lengths are asked for while this one's suffix bytes are on their way
+        int32_t ns, np;
+        next_lens(base + nb, nb, cur_s, cur_p, ns, np);
+        if (live) area[i + 1u] = o1;  // behind the loads above: slot i + 1 held the next value's suffix length
 #pragma unroll
         for (uint32_t u = 0; u < 3u; ++u) {
             const uint32_t q = (uint32_t)lane + kWave * u;
@@ -515,7 +517,7 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
         }
         wave_sync();
 
-        const uint32_t srcb = shift + (sincl - s);       // sbuf index of this value's suffix (sbuf = obuf + kBaOutWin)
+        const uint32_t srcb = shift + (sincl32 - s);     // sbuf index of this value's suffix (sbuf = obuf + kBaOutWin)
         const uint32_t srcp = srcb - p;                  // ... of its position 0, were the suffix the whole value
         const uint32_t ob = dlow + o0;                   // window index (mod its size) of the value's position 0
         const uint32_t pb = dlow + o_prev;               // ... of the value in front of the batch
@@ -554,7 +556,8 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
         wave_sync();
 
         // whole 16-byte pieces of [flushed, o_end) go to memory; the rest waits for the next batch
-        const bool last = base + nb >= done;
+        const bool failing_here = fm != 0ull && nb == good;  // the value behind this batch is the one that fails
+        const bool last = base + nb >= m || failing_here;
         uint32_t f = flushed;
         const uint32_t head = min((16u - ((dlow + f) & 15u)) & 15u, o_end - f);
         if ((uint32_t)lane < head) data[f + lane] = obuf[(dlow + f + (uint32_t)lane) & (kBaOutWin - 1u)];
@@ -576,13 +579,19 @@ __device__ __forceinline__ ByteArrayResult delta_ba_wave(uint32_t *window, const
         }
         flushed = f;
         o_prev = (uint32_t)__builtin_amdgcn_readlane((int)o0, (int)(nb - 1u));
+        prev_len = (uint32_t)__builtin_amdgcn_readlane((int)vlen, (int)(nb - 1u));
         prev_in_lds = true;
         sc += stot;
+        oc = (uint64_t)o_end;
         base += nb;
-        o0 = n0;
-        o1 = n1;
-        pr = np;
+        if (!failing_here) res.consumed = init_consumed + sc;
+        stop = failing_here;
+        cur_s = ns;
+        cur_p = np;
     }
+    if (status == PQ_OK && n > total) status = PQ_EOF;  // next() past the last length (:205-207)
+    res.status = status;
+    res.n_decoded = status == PQ_BYTE_ARRAY_INVALID_PREFIX ? 0u : base;  // "return 0, err" (:330)
     return res;
 }
 
