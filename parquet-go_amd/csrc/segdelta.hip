@@ -203,6 +203,67 @@ __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int
             const uint32_t lim = left > (int64_t)kDwChunk ? (uint32_t)kDwChunk : (left < 0 ? 0u : (uint32_t)left);
             const uint32_t o_max = tail ? 0x7fffffffu : (uint32_t)(kDwChunk - kDwBlockMax);
             uint32_t hdr_lo = 0, vl = 0, bad = 0;
+            {
+                // Two blocks an iteration, entirely on the vector unit, as the decode of 4-byte values
+                // does it (delta_pair_loop): lanes 0..31 take the first block, lanes 32..63 the one
+                // behind it, four values each; nothing is scanned or stored, a lane just adds up what
+                // it unpacks.  Takes pairs of plain blocks that lie whole inside the window and the
+                // segment; whatever ends it is the single-block loop's business.
+                const bool upper = lane >= 32;
+                const uint32_t j = (uint32_t)lane & 31u;
+                const uint32_t sh8p = (j >> 3) * 8u;  // 8 * the miniblock of this lane's 4 values
+                const uint32_t k4 = 4u * (j & 7u);    // index of the first of them inside the miniblock
+                const uint32_t o_max2 = tail ? 0x7fffffffu : (uint32_t)(kDwChunk - 2 * kDwBlockMax);
+                while (o <= o_max2) {
+                    uint32_t next_a;
+                    {
+                        const uint32_t k = o >> 2;
+                        const uint32_t d0 = lds[k], d1 = lds[k + 1], d2 = lds[k + 2];
+                        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, o * 8u);
+                        const uint32_t mid = __builtin_amdgcn_alignbit(d2, d1, o * 8u);
+                        const uint32_t end = ~lo & 0x80808080u;
+                        const uint32_t vla = ((uint32_t)__builtin_ctz(end | 0x80000000u) + 1u) >> 3;
+                        const uint32_t wa = (uint32_t)(((((uint64_t)mid) << 32) | lo) >> (8u * vla));
+                        next_a = o + vla + 4u + 4u * __builtin_amdgcn_sad_u8(wa, 0u, 0u);
+                    }
+                    // a first header that is not a plain one sends the second half anywhere: keep its reads inside the window
+                    const uint32_t ho = upper ? min(next_a, (uint32_t)kDwChunk) : o;
+                    const uint32_t k = ho >> 2;
+                    const uint32_t d0 = lds[k], d1 = lds[k + 1], d2 = lds[k + 2];
+                    const uint32_t h_lo = __builtin_amdgcn_alignbit(d1, d0, ho * 8u);
+                    const uint32_t mid = __builtin_amdgcn_alignbit(d2, d1, ho * 8u);
+                    const uint32_t end = ~h_lo & 0x80808080u;
+                    const uint32_t vlp = ((uint32_t)__builtin_ctz(end | 0x80000000u) + 1u) >> 3;  // 1..4
+                    const uint32_t widths = (uint32_t)(((((uint64_t)mid) << 32) | h_lo) >> (8u * vlp));
+                    const uint32_t data = ho + vlp + 4u;
+                    const uint32_t next = data + 4u * __builtin_amdgcn_sad_u8(widths, 0u, 0u);
+                    // minDelta of five bytes and more, a width above 32, a block that is not all in the
+                    // window, a block that belongs to the next segment
+                    const bool pbad = end == 0u || ((((widths & 0x7f7f7f7fu) + 0x5f5f5f5fu) | widths) & 0x80808080u) != 0u ||
+                                      next > lim || (int32_t)(ho + vlp) >= hi_rel;
+                    if (__builtin_amdgcn_ballot_w64(pbad) != 0ull) break;
+                    const uint32_t mv = h_lo & (0xffffffffu >> (32u - 8u * vlp));
+                    const uint32_t mx = (mv & 0x7fu) | ((mv >> 1) & 0x3f80u) | ((mv >> 2) & 0x1fc000u) | ((mv >> 3) & 0xfe00000u);
+                    const int32_t mdp = ((int32_t)(mx >> 1) ^ -(int32_t)(mx & 1u)) & (int32_t)(upper ? 0xffffffffu : md_mask);
+                    const uint32_t w = __builtin_amdgcn_ubfe(widths, sh8p, 8u);
+                    const uint32_t sum2 = widths + (widths << 8);
+                    const uint32_t sums = sum2 + (sum2 << 16);
+                    const uint32_t pre = __builtin_amdgcn_ubfe(sums << 8, sh8p, 8u);
+                    const uint32_t bit = data * 8u + (pre << 5) + __umul24(k4, w);
+                    const uint32_t m = (uint32_t)(1ull << w) - 1u;  // w == 32 -> 0xffffffff, w == 0 -> 0
+                    uint64_t four = (uint64_t)(4ll * (int64_t)mdp);
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; ++q) {
+                        const uint32_t bq = bit + q * w;
+                        const uint32_t i = bq >> 5;
+                        four += (uint64_t)(__builtin_amdgcn_alignbit(lds[i + 1], lds[i], bq) & m);
+                    }
+                    acc += four;
+                    md_mask = 0xffffffffu;
+                    nblk += 2u;
+                    o = (uint32_t)__builtin_amdgcn_readlane((int)next, 63);
+                }
+            }
             while (o <= o_max) {
                 const uint32_t k = o >> 2, sh = (o & 3u) * 8u;
                 const uint32_t d0 = uni(lds[k]), d1 = uni(lds[k + 1]), d2 = uni(lds[k + 2]);
