@@ -109,11 +109,12 @@ int pq_ctx_synchronize(pq_ctx *ctx);
  * its large ones decoded in segments, many waves to a page (a page is one serial chain of blocks,
  * encoding/delta-binary-packed-decoder.go:130-147; a few large pages would otherwise leave most of
  * the machine idle; measured on MI355X the cut pays below about 1000 pages, whatever their size).
- * Only blocks whose minDelta varint has at most 4 bytes and whose miniblock widths are at most 32
- * can be skipped over without decoding them: a page is cut up to its first block that is wider (an
- * INT64 column with deltas of 2^32 and more is rejected by the reference anyway,
- * encoding/delta-binary-packed-decoder.go:78-88; one whose minDelta exceeds 2^27 in size is decoded
- * from that block on by one wave).  Data pages of flat columns (PQ_KIND_PAGE_V1/_V2 with
+ * Only blocks whose miniblock widths are at most 32 can be stepped over without decoding them: a
+ * page is cut up to its first block that is wider, and a page whose first block is wider is not cut
+ * (the reference rejects such a block in INT64 columns too,
+ * encoding/delta-binary-packed-decoder.go:78-88).  A minDelta of any size is stepped over (five
+ * varint bytes and more: INT64 columns that grow by 2^27 and more a value, at about half the rate
+ * of shorter ones); in INT32 columns and in blocks of 256 values only up to four bytes.  Data pages of flat columns (PQ_KIND_PAGE_V1/_V2 with
  * max_rep == 0, max_def == 0) are cut like the bare streams of their value encoding.
  * Dictionary-index pages (PQ_KIND_DICT) and raw hybrid streams (PQ_KIND_HYBRID without flags)
  * whose runs are bit-packed runs of one repeated length (encoding/hybrid-decoder.go:111-136) are cut

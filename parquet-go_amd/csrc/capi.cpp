@@ -1178,7 +1178,13 @@ int finish_slot(pq_ctx *ctx, ChunkSlot &sl, bool pinned)
     if (!sl.job) return PQ_OK;
     pq_chunk_job &j = *sl.job;
     sl.job = nullptr;
-    PQ_HIP(ctx, hipEventSynchronize(sl.done));
+    if (!hip_ok(ctx, hipEventSynchronize(sl.done), "hipEventSynchronize")) {
+        // the job's outputs are not to be trusted; its plan goes all the same
+        j.status = PQ_ERR_HIP;
+        pq_plan_destroy(sl.plan);
+        sl.plan = nullptr;
+        return PQ_ERR_HIP;
+    }
     if (!pinned) {
         const char *out = static_cast<const char *>(sl.pin_out);
         if (j.values_bytes) par_copy(j.values, out, j.values_bytes);
@@ -1187,6 +1193,47 @@ int finish_slot(pq_ctx *ctx, ChunkSlot &sl, bool pinned)
     std::memcpy(j.results, static_cast<const char *>(sl.pin_out) + sl.off_results, j.n_pages * sizeof(pq_page_result));
     pq_plan_destroy(sl.plan);
     sl.plan = nullptr;
+    return PQ_OK;
+}
+
+// The queued part of a job: copies in on the one stream, the decode on the slot's, copies out on the
+// other.  The slot's device buffers are free: the job that used them last has been waited for.
+// Returns a HIP failure; a job the run refuses (a descriptor points outside its buffers) has its
+// status set and PQ_OK returned: the other jobs go on.
+int queue_job(pq_ctx *ctx, ChunkSlot &sl, pq_chunk_job &j, bool pinned, size_t off_dict)
+{
+    pq_ctx *sub = sl.sub;
+    const void *h_src = j.src, *h_dict = j.dict;
+    if (!pinned) {
+        char *in = static_cast<char *>(sl.pin_in);
+        if (j.src_bytes) par_copy(in, j.src, j.src_bytes);
+        if (j.dict_bytes) std::memcpy(in + off_dict, j.dict, j.dict_bytes);
+        h_src = in;
+        h_dict = in + off_dict;
+    }
+    if (j.src_bytes) PQ_HIP(ctx, hipMemcpyAsync(sub->stage[0], h_src, j.src_bytes, hipMemcpyHostToDevice, ctx->chunk_in));
+    if (j.dict_bytes) PQ_HIP(ctx, hipMemcpyAsync(sub->stage[3], h_dict, j.dict_bytes, hipMemcpyHostToDevice, ctx->chunk_in));
+    PQ_HIP(ctx, hipEventRecord(sl.copied_in, ctx->chunk_in));
+    hipStream_t s = sub->stream;
+    PQ_HIP(ctx, hipStreamWaitEvent(s, sl.copied_in, 0));
+    const int st = pq_plan_run(sl.plan, sub->stage[0], j.src_bytes, sub->stage[1], j.values_bytes, sub->stage[2], j.levels_bytes,
+                     sub->stage[3], j.dict_bytes);
+    if (st != PQ_OK) {
+        j.status = st;
+        if (st == PQ_ERR_HIP) ctx->last_error = sub->last_error;
+        return st == PQ_ERR_HIP ? st : PQ_OK;
+    }
+    PQ_HIP(ctx, hipEventRecord(sl.decoded, s));
+    PQ_HIP(ctx, hipStreamWaitEvent(ctx->chunk_out, sl.decoded, 0));
+    char *out = static_cast<char *>(sl.pin_out);
+    void *h_values = pinned ? j.values : out, *h_levels = pinned ? j.levels : out + sl.off_levels;
+    if (j.values_bytes)
+        PQ_HIP(ctx, hipMemcpyAsync(h_values, sub->stage[1], j.values_bytes, hipMemcpyDeviceToHost, ctx->chunk_out));
+    if (j.levels_bytes)
+        PQ_HIP(ctx, hipMemcpyAsync(h_levels, sub->stage[2], j.levels_bytes, hipMemcpyDeviceToHost, ctx->chunk_out));
+    PQ_HIP(ctx, hipMemcpyAsync(out + sl.off_results, sl.plan->d_results, j.n_pages * sizeof(pq_page_result),
+                               hipMemcpyDeviceToHost, ctx->chunk_out));
+    PQ_HIP(ctx, hipEventRecord(sl.done, ctx->chunk_out));
     return PQ_OK;
 }
 
@@ -1206,6 +1253,7 @@ int start_slot(pq_ctx *ctx, ChunkSlot &sl, pq_chunk_job &j, bool pinned)
         const int st = ensure_stage(sub, i, sizes[i] + 16);
         if (st != PQ_OK) {
             ctx->last_error = sub->last_error;
+            j.status = st;
             return st;
         }
     }
@@ -1214,7 +1262,10 @@ int start_slot(pq_ctx *ctx, ChunkSlot &sl, pq_chunk_job &j, bool pinned)
     int st = ensure_pinned(ctx, &sl.pin_out, &sl.pin_out_cap, sl.off_results + j.n_pages * sizeof(pq_page_result));
     const size_t off_dict = up256(j.src_bytes);
     if (st == PQ_OK && !pinned) st = ensure_pinned(ctx, &sl.pin_in, &sl.pin_in_cap, off_dict + j.dict_bytes);
-    if (st != PQ_OK) return st;
+    if (st != PQ_OK) {
+        j.status = st;
+        return st;
+    }
     st = pq_plan_create(sub, j.descs, j.n_pages, &sl.plan);  // before anything is queued: it may refuse the job
     if (st != PQ_OK) {
         j.status = st;
@@ -1222,42 +1273,17 @@ int start_slot(pq_ctx *ctx, ChunkSlot &sl, pq_chunk_job &j, bool pinned)
         if (st == PQ_ERR_HIP) ctx->last_error = sub->last_error;
         return st == PQ_ERR_HIP ? st : PQ_OK;
     }
-    const void *h_src = j.src, *h_dict = j.dict;
-    if (!pinned) {
-        char *in = static_cast<char *>(sl.pin_in);
-        if (j.src_bytes) par_copy(in, j.src, j.src_bytes);
-        if (j.dict_bytes) std::memcpy(in + off_dict, j.dict, j.dict_bytes);
-        h_src = in;
-        h_dict = in + off_dict;
-    }
-    // copies in on the one stream, the decode on the slot's, copies out on the other; the slot's
-    // device buffers are free: the job that used them last has been waited for
-    if (j.src_bytes) PQ_HIP(ctx, hipMemcpyAsync(sub->stage[0], h_src, j.src_bytes, hipMemcpyHostToDevice, ctx->chunk_in));
-    if (j.dict_bytes) PQ_HIP(ctx, hipMemcpyAsync(sub->stage[3], h_dict, j.dict_bytes, hipMemcpyHostToDevice, ctx->chunk_in));
-    PQ_HIP(ctx, hipEventRecord(sl.copied_in, ctx->chunk_in));
-    hipStream_t s = sub->stream;
-    PQ_HIP(ctx, hipStreamWaitEvent(s, sl.copied_in, 0));
-    st = pq_plan_run(sl.plan, sub->stage[0], j.src_bytes, sub->stage[1], j.values_bytes, sub->stage[2], j.levels_bytes,
-                     sub->stage[3], j.dict_bytes);
-    if (st != PQ_OK) {  // a descriptor points outside the job's buffers: the other jobs go on
-        j.status = st;
-        PQ_HIP(ctx, hipStreamSynchronize(ctx->chunk_in));  // the copies in still read the slot's staging
+    // from here on the slot owns a plan: whatever fails, it is destroyed before the slot is used again
+    const int qs = queue_job(ctx, sl, j, pinned, off_dict);
+    if (qs != PQ_OK || j.status != PQ_OK) {
+        (void)hipStreamSynchronize(ctx->chunk_in);  // copies in may still read the slot's staging
+        (void)hipStreamSynchronize(sub->stream);
+        (void)hipStreamSynchronize(ctx->chunk_out);
         pq_plan_destroy(sl.plan);
         sl.plan = nullptr;
-        if (st == PQ_ERR_HIP) ctx->last_error = sub->last_error;
-        return st == PQ_ERR_HIP ? st : PQ_OK;
+        if (qs != PQ_OK) j.status = qs;
+        return qs;
     }
-    PQ_HIP(ctx, hipEventRecord(sl.decoded, s));
-    PQ_HIP(ctx, hipStreamWaitEvent(ctx->chunk_out, sl.decoded, 0));
-    char *out = static_cast<char *>(sl.pin_out);
-    void *h_values = pinned ? j.values : out, *h_levels = pinned ? j.levels : out + sl.off_levels;
-    if (j.values_bytes)
-        PQ_HIP(ctx, hipMemcpyAsync(h_values, sub->stage[1], j.values_bytes, hipMemcpyDeviceToHost, ctx->chunk_out));
-    if (j.levels_bytes)
-        PQ_HIP(ctx, hipMemcpyAsync(h_levels, sub->stage[2], j.levels_bytes, hipMemcpyDeviceToHost, ctx->chunk_out));
-    PQ_HIP(ctx, hipMemcpyAsync(out + sl.off_results, sl.plan->d_results, j.n_pages * sizeof(pq_page_result),
-                               hipMemcpyDeviceToHost, ctx->chunk_out));
-    PQ_HIP(ctx, hipEventRecord(sl.done, ctx->chunk_out));
     sl.job = &j;
     return PQ_OK;
 }
@@ -1285,12 +1311,15 @@ int pq_decode_chunks(pq_ctx *ctx, pq_chunk_job *jobs, size_t n_jobs, uint32_t fl
         sl.sub->hybrid_wave_min_pages = ctx->hybrid_wave_min_pages;
         sl.sub->seg_max_pages = ctx->seg_max_pages;
         sl.sub->seg_bytes = ctx->seg_bytes;
+        sl.sub->seg_spin_limit = ctx->seg_spin_limit;
         if (!sl.done) PQ_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         if (!sl.copied_in) PQ_HIP(ctx, hipEventCreateWithFlags(&sl.copied_in, hipEventDisableTiming));
         if (!sl.decoded) PQ_HIP(ctx, hipEventCreateWithFlags(&sl.decoded, hipEventDisableTiming));
     }
     if (!ctx->chunk_in) PQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->chunk_in, hipStreamNonBlocking));
     if (!ctx->chunk_out) PQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->chunk_out, hipStreamNonBlocking));
+    // a job that is never started (a HIP failure ends the loop) says so
+    for (size_t i = 0; i < n_jobs; ++i) jobs[i].status = PQ_ERR_HIP;
     int rc = PQ_OK;
     for (size_t i = 0; i < n_jobs && rc == PQ_OK; ++i) {
         ChunkSlot &sl = ctx->slots[i % n_slots];

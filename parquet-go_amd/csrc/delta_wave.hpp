@@ -527,6 +527,37 @@ __device__ __forceinline__ void delta_pair_loop(const uint32_t *lds, UT *dst, ui
     }
 }
 
+// A block header whose minDelta varint has five to ten bytes (2^27 and more in size), put together
+// on the scalar unit: hdr_lo / mid = bytes 0..3 / 4..7 of the header, found at byte shift sh of LDS
+// word k, h2 = word k + 2.  false: no end within ten bytes, or more than 64 bits (errors the
+// checked path reports).  widths = the four bytes behind the varint.
+__device__ __forceinline__ bool wave_long_min_delta(const uint32_t *lds, uint32_t k, uint32_t sh, uint32_t hdr_lo, uint32_t mid,
+                                                    uint32_t h2, uint32_t &vl, uint32_t &widths, int64_t &md)
+{
+    const uint32_t h3 = uni(lds[k + 3]), h4 = uni(lds[k + 4]);
+    const uint32_t hi = (uint32_t)(((((uint64_t)h3) << 32) | h2) >> sh);    // bytes 8..11
+    const uint32_t top = (uint32_t)(((((uint64_t)h4) << 32) | h3) >> sh);  // bytes 12..15
+    const uint32_t end2 = ~mid & 0x80808080u, end3 = ~hi & 0x00008080u;
+    vl = 4u;
+    widths = 0u;
+    md = 0;
+    if (end2 == 0u && end3 == 0u) return false;
+    vl = end2 != 0u ? 4u + (((uint32_t)__builtin_ctz(end2) + 1u) >> 3) : 8u + (((uint32_t)__builtin_ctz(end3) + 1u) >> 3);  // 5..10
+    auto seven = [](uint32_t v) -> uint64_t {
+        return (v & 0x7fu) | ((v >> 1) & 0x3f80u) | ((v >> 2) & 0x1fc000u) | ((v >> 3) & 0xfe00000u);
+    };
+    const uint32_t mid_v = vl >= 8u ? mid : mid & (0xffffffffu >> (64u - 8u * vl));
+    const uint32_t hi_v = vl > 8u ? hi & (0xffffu >> (80u - 8u * vl)) : 0u;
+    if (vl == 10u && (hi_v >> 8) > 1u) return false;
+    const uint64_t zz = seven(hdr_lo) | (seven(mid_v) << 28) | (seven(hi_v) << 56);
+    md = (int64_t)(zz >> 1) ^ -(int64_t)(zz & 1ull);
+    // the width bytes behind the varint: bytes vl .. vl + 3 of the sixteen at hand
+    const uint64_t lo64 = (((uint64_t)mid) << 32) | hdr_lo, hi64 = (((uint64_t)top) << 32) | hi;
+    const uint32_t sv = 8u * vl;  // 40..80
+    widths = sv < 64u ? (uint32_t)((lo64 >> sv) | (hi64 << (64u - sv))) : (uint32_t)(hi64 >> (sv - 64u));
+    return true;
+}
+
 struct WaveDeltaResult {
     int32_t status; // PQ_*, or kNeedGeneric when the layout is not 128 / 4
     uint32_t n_decoded;
@@ -621,7 +652,7 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
                                                   tail ? 0x7fffffffu : (uint32_t)(kDwChunk - 2 * kDwBlockMax), stop_rel, wo, lane);
                 }
                 // one block behind its header: widths (a byte per miniblock), window offset of its data, minDelta
-                auto emit_block = [&](uint32_t widths, uint32_t data, int32_t md, uint32_t vl) {
+                auto emit_block = [&](uint32_t widths, uint32_t data, int64_t md, uint32_t vl) {
                         // every width <= 23 and a minDelta of at most three bytes: a tile's partial sums
                         // fit 32 bits (see wave_decode_tile)
                         const bool narrow = (((widths & 0x7f7f7f7fu) + 0x68686868u) & 0x80808080u) == 0u && vl <= 3u;
@@ -644,15 +675,15 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
                             if constexpr (sizeof(UT) == 8) {
                                 UT v0, v1;
                                 if (narrow) {
-                                    const int32_t da = (int32_t)ua + md;
-                                    const int32_t pair = da + (int32_t)ub + md;
+                                    const int32_t da = (int32_t)ua + (int32_t)md;
+                                    const int32_t pair = da + (int32_t)ub + (int32_t)md;
                                     const int32_t incl = (int32_t)wave_scan_u32((uint32_t)pair);
                                     v0 = carry + (UT)(int64_t)(incl - pair);
                                     v1 = v0 + (UT)(int64_t)da;
                                     carry += (UT)(int64_t)(int32_t)wave_last_u32((uint32_t)incl);
                                 } else {
-                                    const UT a = (UT)ua + (UT)(int64_t)md;
-                                    const UT pair = a + (UT)ub + (UT)(int64_t)md;
+                                    const UT a = (UT)ua + (UT)md;
+                                    const UT pair = a + (UT)ub + (UT)md;
                                     const UT incl = wave_scan_u64(pair);
                                     v0 = carry + (incl - pair);
                                     v1 = v0 + a;
@@ -740,6 +771,21 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
                     const uint32_t hdr_lo = (uint32_t)(((((uint64_t)h1) << 32) | h0) >> sh);
                     const uint32_t mid = (uint32_t)(((((uint64_t)h2) << 32) | h1) >> sh);
                     const uint32_t end = ~hdr_lo & 0x80808080u;
+                    if constexpr (sizeof(UT) == 8) {
+                        if (end == 0u) {
+                            // A minDelta of 2^27 and more (a column of nanosecond timestamps a second apart)
+                            uint32_t vl, widths;
+                            int64_t md;
+                            if (!wave_long_min_delta(lds, k, sh, hdr_lo, mid, h2, vl, widths, md)) break;  // the checked path says what it is
+                            const uint32_t data = o + vl + 4u;
+                            const uint32_t next = data + ((((widths * 0x01010101u) >> 24) << LG) >> 3);
+                            if (((((widths & 0x7f7f7f7fu) + 0x5f5f5f5fu) | widths) & 0x80808080u) != 0u || next > lim) break;
+                            emit_block(widths, data, md, vl);
+                            o = next;
+                            p0 += kBlockValues;
+                            continue;
+                        }
+                    }
                     const uint32_t vl = ((uint32_t)__builtin_ctz(end | 0x80000000u) + 1u) >> 3;  // 1..4
                     const uint32_t widths = (uint32_t)(((((uint64_t)mid) << 32) | hdr_lo) >> (8u * vl));
                     const uint32_t data = o + vl + 4u;

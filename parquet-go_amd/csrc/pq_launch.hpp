@@ -112,9 +112,8 @@ static_assert(sizeof(SegRec) == 64, "segment records are 64 bytes");
 // has the layout of the words).  A segment first shows a summary of its own walk (a0..a2), later
 // its place in the page (p0..p2: everything up to its end).
 struct SegLook {
-    uint64_t a0, a1, a2;
-    uint64_t p0, p1, p2;
-    uint64_t pad[2];
+    uint64_t a0, a1, a2, a3;
+    uint64_t p0, p1, p2, p3;
 };
 static_assert(sizeof(SegLook) == 64, "look-back records are 64 bytes");
 constexpr uint32_t kSegSpinLimit = 1u << 20;  // looks a wave takes at the segments in front of it before it gives up

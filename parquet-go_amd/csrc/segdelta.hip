@@ -76,6 +76,20 @@ __global__ __launch_bounds__(kWave) void seg_header_kernel(const pq_page_desc *_
     if (hs == PQ_OK && !((bs == 128u || bs == 256u) && nm == 4u)) hs = PQ_INVALID_BLOCK_SIZE;
     const uint64_t need = total < (uint64_t)d.n_values ? total : (uint64_t)d.n_values;
     if (hs == PQ_OK && need < 2u * bs) hs = PQ_EOF;  // nothing to gain
+    if (hs == PQ_OK) {
+        // A sample: the first block.  The walks step over blocks whose widths are at most 32 (the
+        // reference takes no others); a page that starts with another kind would have every wave
+        // but the first scan its segment for nothing.
+        int64_t p2 = pos;
+        uint32_t vl = 0;
+        while (vl < 10u && p2 < len && (S[p2] & 0x80u) != 0u) {
+            ++p2;
+            ++vl;
+        }
+        bool plain = vl < 10u && p2 + 5 <= len;
+        for (int k = 1; plain && k <= 4; ++k) plain = S[p2 + k] <= 32u;
+        if (!plain) hs = PQ_EOF;
+    }
     pg.whole = hs == PQ_OK ? 0u : 1u;
     pg.lg = bs == 256u ? 6u : 5u;
     pg.total = (uint32_t)total;
@@ -102,7 +116,7 @@ struct SegScan {
     uint32_t nblk;      // blocks walked
     uint32_t exit_key;  // width bytes of the header at exit_off
     uint64_t sum;       // sum of the walked deltas, without the first block's minDelta (segment 0: with it)
-    uint32_t exit_md;   // minDelta of the header at exit_off
+    int64_t exit_md;    // minDelta of the header at exit_off
 };
 
 template <uint32_t LG>
@@ -175,7 +189,7 @@ __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int
         }
     }
     key = uni(key);
-    if (key == kSegNone) return SegScan{kSegNone, kSegNone, 0u, kSegNone, 0ull, 0u};
+    if (key == kSegNone) return SegScan{kSegNone, kSegNone, 0u, kSegNone, 0ull, 0};
 
     // whole blocks from there to the first block whose width bytes are at or behind `hi` (a
     // segment owns the blocks whose width bytes start in it).  The walk starts one byte in
@@ -187,7 +201,8 @@ __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int
     WaveBlock blk{0, 0, 0, 0, 0, 0};
     uint64_t acc = 0;      // per lane: the deltas it unpacked, minDelta included except in the first
                            // block's tiles (segment 0: there too)
-    uint32_t nblk = 0, exit_off = kSegNone, exit_key = kSegNone, exit_md = 0;
+    uint32_t nblk = 0, exit_off = kSegNone, exit_key = kSegNone;
+    int64_t exit_md = 0;
     uint32_t o = (uint32_t)((s == 0u ? (int64_t)pos0 : (int64_t)key - 1) - c0), p0 = 0;  // segment 0 knows its header
     bool done = false;
     int32_t hi_rel = (int32_t)(hi - c0);  // `hi` as a window offset
@@ -203,6 +218,8 @@ __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int
             const uint32_t lim = left > (int64_t)kDwChunk ? (uint32_t)kDwChunk : (left < 0 ? 0u : (uint32_t)left);
             const uint32_t o_max = tail ? 0x7fffffffu : (uint32_t)(kDwChunk - kDwBlockMax);
             uint32_t hdr_lo = 0, vl = 0, bad = 0;
+            bool lng = false;     // the header's minDelta varint has five bytes or more ...
+            int64_t md_long = 0;  // ... and this value
             {
                 // Two blocks an iteration, entirely on the vector unit, as the decode of 4-byte values
                 // does it (delta_pair_loop): lanes 0..31 take the first block, lanes 32..63 the one
@@ -270,12 +287,18 @@ __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int
                 hdr_lo = (uint32_t)(((((uint64_t)d1) << 32) | d0) >> sh);
                 const uint32_t mid = (uint32_t)(((((uint64_t)d2) << 32) | d1) >> sh);
                 const uint32_t stop = ~hdr_lo & 0x80808080u;
-                vl = ((uint32_t)__builtin_ctz(stop | 0x80000000u) + 1u) >> 3;  // 1..4 (4 also when there is no end)
-                const uint32_t widths = (uint32_t)(((((uint64_t)mid) << 32) | hdr_lo) >> (8u * vl));
+                uint32_t widths;
+                lng = false;
+                if (stop != 0u) {
+                    vl = ((uint32_t)__builtin_ctz(stop) + 1u) >> 3;  // 1..4
+                    widths = (uint32_t)(((((uint64_t)mid) << 32) | hdr_lo) >> (8u * vl));
+                } else {
+                    lng = wave_long_min_delta(lds, k, sh, hdr_lo, mid, d2, vl, widths, md_long);  // five to ten bytes
+                }
                 const uint32_t data = o + vl + 4u;
                 const uint32_t next = data + 4u * ((widths * 0x01010101u) >> 24);
-                // a minDelta of five bytes or more, a width above 32, a block that is not all there
-                bad = (stop == 0u ? 1u : 0u) | (((((widths & 0x7f7f7f7fu) + 0x5f5f5f5fu) | widths) & 0x80808080u) != 0u ? 1u : 0u) |
+                // a minDelta that is no varint of 64 bits, a width above 32, a block that is not all there
+                bad = (stop == 0u && !lng ? 1u : 0u) | (((((widths & 0x7f7f7f7fu) + 0x5f5f5f5fu) | widths) & 0x80808080u) != 0u ? 1u : 0u) |
                       (next > lim ? 1u : 0u);
                 if (bad != 0u || (int32_t)(o + vl) >= hi_rel) break;
                 const uint32_t w = __builtin_amdgcn_ubfe(widths, ln.sh8, 8u);
@@ -289,8 +312,8 @@ __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int
                 const uint32_t ua = l32 & m;
                 const uint32_t ub = (uint32_t)((((uint64_t)h32 << 32) | l32) >> w) & m;
                 // minDelta twice per lane (its two values), expanded on the vector unit like the decode does
-                const int32_t md = wave_expand_min_delta(hdr_lo, vl) & (int32_t)md_mask;
-                acc += (uint64_t)ua + (uint64_t)ub + (uint64_t)(2ll * (int64_t)md);
+                const int64_t md = md_mask == 0u ? 0ll : (lng ? md_long : (int64_t)wave_expand_min_delta(hdr_lo, vl));
+                acc += (uint64_t)ua + (uint64_t)ub + 2ull * (uint64_t)md;
                 md_mask = 0xffffffffu;
                 nblk += 1u;
                 o = next;
@@ -301,7 +324,7 @@ __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int
                     // width bytes are, and its minDelta
                     exit_off = (uint32_t)(c0 + (int64_t)o);
                     exit_key = exit_off + vl;
-                    exit_md = (uint32_t)(int32_t)wave_raw_min_delta(hdr_lo, vl);
+                    exit_md = lng ? md_long : wave_raw_min_delta(hdr_lo, vl);
                 }
                 break;  // else: not a whole, plain block; the walk (and the chain of proofs) ends here
             }
@@ -331,7 +354,7 @@ __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int
                 if (header && at + (int64_t)t.vl >= hi) {
                     exit_off = (uint32_t)at;
                     exit_key = exit_off + t.vl;
-                    exit_md = (uint32_t)(int32_t)wave_raw_min_delta(t.hdr_lo, t.vl);
+                    exit_md = wave_raw_min_delta(t.hdr_lo, t.vl);
                     done = true;
                     break;
                 }
@@ -358,7 +381,8 @@ __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int
         }
     }
     const uint64_t total = wave_last_u64(wave_scan_u64(acc));
-    return SegScan{key, uni(exit_off), uni(nblk), uni(exit_key), total, uni(exit_md)};
+    return SegScan{key, uni(exit_off), uni(nblk), uni(exit_key), total,
+                   (int64_t)(((uint64_t)uni((uint32_t)((uint64_t)exit_md >> 32)) << 32) | uni((uint32_t)exit_md))};
 }
 
 // ---- what segments show each other ------------------------------------------------------------
@@ -367,13 +391,14 @@ __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int
 // show that bit.  Words are stored and loaded with relaxed agent-scope atomics and nothing else:
 // no fence, so no cache is written back or thrown away while the decode's output streams through.
 //   summary  a0: key | blocks walked << 32 | bit 63 of the sum << 56
-//            a1: header the walk ended on | bytes of its minDelta varint << 32 | its minDelta (28 bits) << 35
+//            a1: header the walk ended on | bytes of its minDelta varint << 32 | bit 63 of that minDelta << 36
 //            a2: bits 0..62 of the sum
+//            a3: bits 0..62 of the minDelta
 //   place    p0: as a1, for the walk that counts (0xffffffff: the page ends with this segment or one
-//                in front; with varint bytes = 7: a wait ran out)
+//                in front; with varint bytes = 15: a wait ran out)
 //            p1: blocks up to there | bit 63 of the carry << 32
 //            p2: bits 0..62 of the carry (first value + every delta up to there)
-// A minDelta that is walked over has at most four varint bytes, so 28 bits hold it.
+//            p3: as a3
 constexpr uint64_t kLookBit = 1ull << 63;
 constexpr uint32_t kLookNone = 0, kLookSummary = 1, kLookPlace = 2, kLookGaveUp = 3;
 
@@ -385,16 +410,18 @@ __device__ __forceinline__ void look_st(uint64_t *p, uint64_t v)
 {
     __hip_atomic_store(p, v | kLookBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ uint64_t look_exit_word(uint32_t exit_off, uint32_t exit_key, uint32_t exit_md)
+// exit word: header | bytes of its minDelta varint (1..10) << 32 | bit 63 of the minDelta << 36; the
+// minDelta's other bits have a word of their own
+__device__ __forceinline__ uint64_t look_exit_word(uint32_t exit_off, uint32_t exit_key, int64_t exit_md)
 {
     if (exit_off == kSegNone) return (uint64_t)kSegNone;
-    return (uint64_t)exit_off | ((uint64_t)((exit_key - exit_off) & 7u) << 32) | ((uint64_t)(exit_md & 0x0fffffffu) << 35);
+    return (uint64_t)exit_off | ((uint64_t)((exit_key - exit_off) & 15u) << 32) | (((uint64_t)exit_md >> 63) << 36);
 }
-__device__ __forceinline__ void look_exit_fields(uint64_t w, uint32_t &exit_off, uint32_t &exit_key, uint32_t &exit_md)
+__device__ __forceinline__ void look_exit_fields(uint64_t w, uint64_t mdw, uint32_t &exit_off, uint32_t &exit_key, int64_t &exit_md)
 {
     exit_off = (uint32_t)w;
-    exit_key = exit_off == kSegNone ? kSegNone : exit_off + ((uint32_t)(w >> 32) & 7u);
-    exit_md = (uint32_t)((int32_t)((uint32_t)(w >> 35) << 4) >> 4);
+    exit_key = exit_off == kSegNone ? kSegNone : exit_off + ((uint32_t)(w >> 32) & 15u);
+    exit_md = (int64_t)((mdw & ~kLookBit) | (((w >> 36) & 1ull) << 63));
 }
 
 // Called by lane 0.
@@ -403,18 +430,21 @@ __device__ __forceinline__ void look_show_summary(SegLook *r, const SegScan &a)
     look_st(&r->a0, (uint64_t)a.key | ((uint64_t)a.nblk << 32) | ((a.sum >> 63) << 56));
     look_st(&r->a1, look_exit_word(a.exit_off, a.exit_key, a.exit_md));
     look_st(&r->a2, a.sum & ~kLookBit);
+    look_st(&r->a3, (uint64_t)a.exit_md & ~kLookBit);
 }
 // exit_off == kSegNone: the segments behind this one have nothing to do.
 __device__ __forceinline__ void look_show_place(SegLook *r, uint64_t blocks, uint64_t carry, uint32_t exit_off,
-                                                uint32_t exit_key, uint32_t exit_md)
+                                                uint32_t exit_key, int64_t exit_md)
 {
+    look_st(&r->p3, (uint64_t)exit_md & ~kLookBit);
     look_st(&r->p0, look_exit_word(exit_off, exit_key, exit_md));
     look_st(&r->p1, (blocks & 0xffffffffull) | ((carry >> 63) << 32));
     look_st(&r->p2, carry & ~kLookBit);
 }
 __device__ __forceinline__ void look_show_gave_up(SegLook *r)
 {
-    look_st(&r->p0, (uint64_t)kSegNone | (7ull << 32));
+    look_st(&r->p3, 0ull);
+    look_st(&r->p0, (uint64_t)kSegNone | (15ull << 32));
     look_st(&r->p1, 0ull);
     look_st(&r->p2, 0ull);
 }
@@ -432,7 +462,7 @@ struct SegIn {
     uint32_t status;    // kInDead: a segment in front decodes to the end of the page; kInGaveUp: a wait ran out
     uint32_t entry;     // stream offset of the header of the segment's first block
     uint32_t want_key;  // ... of that block's width bytes
-    uint32_t md;        // that block's minDelta
+    int64_t md;         // that block's minDelta
     uint64_t blocks;    // blocks in front of the segment
     uint64_t carry;     // first value + every delta in front of the segment
 };
@@ -445,14 +475,15 @@ struct SegIn {
 // one is looked at again, next to the segment in front of it).
 __device__ __forceinline__ SegIn seg_look_back(const SegLook *L, uint32_t s, int lane, uint64_t V, uint32_t spin_limit)
 {
-    SegIn in{kInGaveUp, 0u, 0u, 0u, 0ull, 0ull};
+    SegIn in{kInGaveUp, 0u, 0u, 0, 0ull, 0ull};
     uint64_t acc_blocks = 0, acc_sum = 0;
     bool first_window = true;
     int64_t j = (int64_t)s - 1;
     uint32_t spins = 0;
     while (true) {
         const int64_t idx = j - lane;
-        uint32_t st = kLookNone, key = kSegNone, nblk = 0, exit_off = kSegNone, exit_key = kSegNone, md = 0, alive = 0;
+        uint32_t st = kLookNone, key = kSegNone, nblk = 0, exit_off = kSegNone, exit_key = kSegNone, alive = 0;
+        int64_t md = 0;
         uint64_t sum = 0, blocks = 0, carry = 0;
         // few lanes at first: every look is a memory transaction per lane that no cache serves
         uint32_t width = first_window ? 8u : (uint32_t)kWave;
@@ -463,20 +494,20 @@ __device__ __forceinline__ SegIn seg_look_back(const SegLook *L, uint32_t s, int
                 const SegLook *r = L + idx;
                 const uint64_t p0 = look_ld(&r->p0);
                 if ((p0 & kLookBit) != 0ull) {
-                    const uint64_t p1 = look_ld(&r->p1), p2 = look_ld(&r->p2);
-                    if ((p1 & p2 & kLookBit) != 0ull) {
-                        look_exit_fields(p0, exit_off, exit_key, md);
+                    const uint64_t p1 = look_ld(&r->p1), p2 = look_ld(&r->p2), p3 = look_ld(&r->p3);
+                    if ((p1 & p2 & p3 & kLookBit) != 0ull) {
+                        look_exit_fields(p0, p3, exit_off, exit_key, md);
                         blocks = p1 & 0xffffffffull;
                         carry = (p2 & ~kLookBit) | ((p1 >> 32) << 63);
                         alive = exit_off != kSegNone ? 1u : 0u;
-                        st = exit_off == kSegNone && ((uint32_t)(p0 >> 32) & 7u) == 7u ? kLookGaveUp : kLookPlace;
+                        st = exit_off == kSegNone && ((uint32_t)(p0 >> 32) & 15u) == 15u ? kLookGaveUp : kLookPlace;
                     }
                 } else if (st == kLookNone) {
-                    const uint64_t a0 = look_ld(&r->a0), a1 = look_ld(&r->a1), a2 = look_ld(&r->a2);
-                    if ((a0 & a1 & a2 & kLookBit) != 0ull) {
+                    const uint64_t a0 = look_ld(&r->a0), a1 = look_ld(&r->a1), a2 = look_ld(&r->a2), a3 = look_ld(&r->a3);
+                    if ((a0 & a1 & a2 & a3 & kLookBit) != 0ull) {
                         key = (uint32_t)a0;
                         nblk = (uint32_t)(a0 >> 32) & 0xffffffu;
-                        look_exit_fields(a1, exit_off, exit_key, md);
+                        look_exit_fields(a1, a3, exit_off, exit_key, md);
                         sum = (a2 & ~kLookBit) | (((a0 >> 56) & 1ull) << 63);
                         st = kLookSummary;
                     }
@@ -512,14 +543,16 @@ __device__ __forceinline__ SegIn seg_look_back(const SegLook *L, uint32_t s, int
         }
         const uint32_t cnt = known != 0ull ? fp : (uint32_t)kWave - 1u;
         const bool mine = (uint32_t)lane < cnt;
-        const uint32_t f_md = (uint32_t)__shfl_down((int)md, 1);  // the first block's minDelta: where the walk in front ended
-        const uint64_t my_sum = mine ? sum + (nblk != 0u ? V * (uint64_t)(int64_t)(int32_t)f_md : 0ull) : 0ull;
+        // the first block's minDelta: where the walk in front ended
+        const uint64_t f_md = ((uint64_t)(uint32_t)__shfl_down((int)(uint32_t)((uint64_t)md >> 32), 1) << 32) |
+                              (uint32_t)__shfl_down((int)(uint32_t)md, 1);
+        const uint64_t my_sum = mine ? sum + (nblk != 0u ? V * f_md : 0ull) : 0ull;
         acc_blocks += wave_sum_u32(mine ? nblk : 0u);
         acc_sum += wave_last_u64(wave_scan_u64(my_sum));
         if (first_window) {
             in.entry = (uint32_t)__builtin_amdgcn_readlane((int)exit_off, 0);
             in.want_key = (uint32_t)__builtin_amdgcn_readlane((int)exit_key, 0);
-            in.md = (uint32_t)__builtin_amdgcn_readlane((int)md, 0);
+            in.md = (int64_t)seg_readlane_u64((uint64_t)md, 0u);
             first_window = false;
         }
         if (known != 0ull) {
@@ -600,7 +633,7 @@ __global__ __launch_bounds__(kWG) void seg_fused_kernel(const pq_page_desc *__re
             blocks = in.blocks;
             carry = in.carry;
             entry = in.entry;
-            a.sum += a.nblk != 0u ? V * (uint64_t)(int64_t)(int32_t)in.md : 0ull;
+            a.sum += a.nblk != 0u ? V * (uint64_t)in.md : 0ull;
         }
         // the last one with a wave of its own: nothing to go on from, or nothing wanted behind it
         tail = a.exit_key == kSegNone || s + 1u == pg.n_segs || V * (blocks + a.nblk) >= (uint64_t)need;
@@ -611,7 +644,7 @@ __global__ __launch_bounds__(kWG) void seg_fused_kernel(const pq_page_desc *__re
             out.nblk = a.nblk;
             out.exit_key = a.exit_key;
             out.sum = a.sum;
-            out.exit_md = a.exit_md;
+            out.exit_md = (uint32_t)a.exit_md;  // its low half
             out.flags = tail ? kSegTail : kSegPart;
             out.value = carry;
             out.entry = entry;

@@ -204,14 +204,15 @@ def bench_levels_stream(ctx, stream, pages, n, max_level, p_max, label, distinct
     plan.close()
 
 
-def bench_delta(ctx, stream, pages, n, bits, width, label="", as_pages=False):
+def bench_delta(ctx, stream, pages, n, bits, width, label="", as_pages=False, stride=-5):
     """as_pages: the same streams as PQ_KIND_PAGE_V1 descriptors of a flat REQUIRED column (what
-    pq_chunks_page_descs makes of a walked chunk) instead of bare PQ_KIND_DELTA32/64."""
+    pq_chunks_page_descs makes of a walked chunk) instead of bare PQ_KIND_DELTA32/64.
+    stride: added to every delta (the blocks' minDelta; 2^27 and more take five varint bytes)."""
     rng = np.random.default_rng(3)
     dt = np.int64 if bits == 64 else np.int32
     streams, keep = [], {}
     for p in range(pages):
-        steps = rng.integers(0, 1 << width, size=n - 1, dtype=np.int64) - 5
+        steps = rng.integers(0, 1 << width, size=n - 1, dtype=np.int64) + stride
         v = np.concatenate([[p * 7], p * 7 + np.cumsum(steps)]).astype(dt)
         if p in (0, pages // 2, pages - 1):
             keep[p] = v
@@ -456,6 +457,9 @@ def main():
             bench_delta(ctx, stream, 1000, 100_000, 64, 16, lab)
             bench_delta(ctx, stream, 100, 1_000_000, 32, 12, lab)
         ctx.set_option(capi.OPT_SEGMENT_MAX_PAGES, 1024)
+    if args.only and want("c2stride"):   # blocks whose minDelta takes five varint bytes and more (nanosecond timestamps)
+        bench_delta(ctx, stream, 100, 1_000_000, 64, 16, ", minDelta 10^9 (5 varint bytes), segmented", stride=10**9)
+        bench_delta(ctx, stream, 8000, 20_000, 64, 16, ", minDelta 10^9 (5 varint bytes), 8000 pages", stride=10**9)
     if args.only and want("c2pages"):   # a parquet-mr style row group: 16 columns x 8 pages x 131 072 int64
         bench_delta(ctx, stream, 128, 131072, 64, 16, ", bare DELTA64 descriptors")
         bench_delta(ctx, stream, 128, 131072, 64, 16, ", PAGE_V1 descriptors of a flat column", as_pages=True)
