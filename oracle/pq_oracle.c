@@ -65,7 +65,14 @@ static int rd_byte(rd_t *r, uint8_t *b)
 /* encoding/binary.ReadUvarint as used by encoding/helpers.go:30,48,66,80:
  * 7 bits per byte, at most 10 bytes, the 10th may only be 0 or 1.  End of input
  * anywhere inside the varint is io.EOF (the behaviour the comment at
- * encoding/hybrid-decoder.go:114-115 relies on). */
+ * encoding/hybrid-decoder.go:114-115 relies on).
+ * Which Go: the standard library's ReadUvarint from Go 1.15 on, which stops after
+ * MaxVarintLen64 = 10 bytes and reports overflow there.  The reference's go.mod names Go 1.14,
+ * whose ReadUvarint goes on reading continuation bytes and reports overflow only at the byte
+ * that ends the varint; the two differ in status and in bytes consumed for inputs of 11 and
+ * more bytes with the top bit set (for example eleven 0x80 and then the end of input: io.EOF
+ * after 11 bytes there, overflow after 10 here).  Any toolchain the reference builds with today
+ * has the newer routine, so that is the one restated here and in the device code. */
 static int read_uvarint(rd_t *r, uint64_t *out)
 {
     uint64_t x = 0;

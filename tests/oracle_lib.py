@@ -10,7 +10,9 @@ import subprocess
 import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_SO = os.path.join(_ROOT, "oracle", "libpqoracle.so")
+# PQ_ORACLE_LIB: another build of the same library (oracle/libpqoracle_asan.so, run with the sanitizer
+# runtime preloaded: LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0)
+_SO = os.environ.get("PQ_ORACLE_LIB") or os.path.join(_ROOT, "oracle", "libpqoracle.so")
 
 # status codes (oracle/pq_oracle.h, enum pqo_status)
 OK, EOF, UNEXPECTED_EOF, EMPTY_BP_RUN, EMPTY_RLE_RUN, RLE_VALUE_TOO_LARGE = 0, 1, 2, 3, 4, 5

@@ -112,7 +112,32 @@ def bench_dict(ctx, stream, pages, n, run_heavy, label, distinct_cap=None):
     plan.close()
 
 
-def bench_bitunpack(ctx, stream, bits, widths, enc_bytes, out_cap=2 << 30):
+def bitunpack_differs(t_src, t_out, w, bits):
+    """How many values of t_out differ from the closed form of the little-endian bit string in t_src
+    (value i = bits [i w, (i + 1) w)), computed with torch on the device, 16 M values at a time."""
+    n = t_out.numel()
+    step = 1 << 24
+    bad = 0
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        bit = torch.arange(lo, hi, dtype=torch.int64, device=DEV) * w
+        byte, sh = bit >> 3, bit & 7
+        lo56 = torch.zeros(hi - lo, dtype=torch.int64, device=DEV)     # bytes 0..6 of the window
+        for b in range(7):
+            lo56 |= t_src[byte + b].to(torch.int64) << (8 * b)
+        v = lo56 >> sh
+        if w > 48:                                                     # up to 7 + 64 bits: two more bytes
+            hi16 = t_src[byte + 7].to(torch.int64) | (t_src[byte + 8].to(torch.int64) << 8)
+            v = v | (hi16 << (56 - sh))                                # wraps mod 2^64, as wanted
+        if w < 64:
+            v = v & ((1 << w) - 1)
+        if bits == 32 and w == 32:
+            v = (v ^ (1 << 31)) - (1 << 31)                            # as int32
+        bad += int((t_out[lo:hi].to(torch.int64) != v).sum().item())
+    return bad
+
+
+def bench_bitunpack(ctx, stream, bits, widths, enc_bytes, out_cap=2 << 30, verify=False):
     rng = np.random.default_rng(4)
     src = rng.integers(0, 256, size=enc_bytes + 64, dtype=np.uint8)
     t_src = torch.from_numpy(src).to(DEV)
@@ -122,9 +147,13 @@ def bench_bitunpack(ctx, stream, bits, widths, enc_bytes, out_cap=2 << 30):
         t_out = torch.empty(ng * 8, dtype=torch.int32 if bits == 32 else torch.int64, device=DEV)
         fn = lambda: ctx.bitunpack_dev(t_src.data_ptr(), ng * w, w, ng, t_out.data_ptr(), bits)
         t = timed(fn, stream, steps=6, warmup=1)
-        report("C3 bitunpack%d w=%d" % (bits, w), ng * w, ng * 8 * es, t,
-               {"groups": ng, "bits": bits, "width": w, "encoded_bytes": ng * w, "decoded_bytes": ng * 8 * es,
-                "output_capped": ng * w < enc_bytes - w})
+        extra = {"groups": ng, "bits": bits, "width": w, "encoded_bytes": ng * w, "decoded_bytes": ng * 8 * es,
+                 "output_capped": ng * w < enc_bytes - w}
+        if verify:
+            differ = bitunpack_differs(t_src, t_out, w, bits)
+            assert differ == 0, ("bitunpack%d w=%d: %d values differ from the closed form" % (bits, w, differ))
+            extra["verified"] = "every value equal to the torch closed form"
+        report("C3 bitunpack%d w=%d" % (bits, w), ng * w, ng * 8 * es, t, extra)
         del t_out
 
 
@@ -422,8 +451,8 @@ def main():
         bench_bitunpack(ctx, stream, 32, [1, 4, 8, 12, 16, 24, 32], 256 << 20)
         bench_bitunpack(ctx, stream, 64, [8, 16, 33, 48, 64], 256 << 20)
     if args.only and want("c3full"):   # every width of both tables, 1 GiB encoded (output capped at 16 GiB)
-        bench_bitunpack(ctx, stream, 32, list(range(1, 33)), 1 << 30, out_cap=16 << 30)
-        bench_bitunpack(ctx, stream, 64, list(range(1, 65)), 1 << 30, out_cap=16 << 30)
+        bench_bitunpack(ctx, stream, 32, list(range(1, 33)), 1 << 30, out_cap=16 << 30, verify=True)
+        bench_bitunpack(ctx, stream, 64, list(range(1, 65)), 1 << 30, out_cap=16 << 30, verify=True)
     if want("c4"):
         bench_nested(ctx, stream, args.pages, 20000)
     if args.only and want("c4big"):   # the large-page variant: 500 pages x 1 M slots (10 distinct pages)
