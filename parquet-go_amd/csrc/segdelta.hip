@@ -4,7 +4,7 @@
 // sum of everything in front).
 //
 // A page of the tiled layouts (blocks of 128 values / 4 miniblocks, or 256 / 4) is cut by BYTES
-// into segments of seg_bytes.  Two launches and a third of one lane per page:
+// into segments of seg_bytes.  Two launches:
 //   1. seg_header_kernel  one lane per page: the stream header (block size, miniblock count,
 //                         value count, first value).
 //   2. seg_fused_kernel   one wave per segment, in three steps.
@@ -28,14 +28,13 @@
 //                walk ended on), which ends the look-back of the waves behind it.  Workgroups start
 //                in the order of their index, so a wave only ever waits for waves that are running
 //                or done; the wait is bounded all the same, and a wave that runs out of patience
-//                leaves its page to the whole-page decoder (seg_post_kernel marks it).
+//                leaves its page to the whole-page decoder (the sweep kernel behind this one; never
+//                seen to happen: it is the exit every wait must have).
 //      decode    the segment's blocks, with the page decoder's own tile loop, up to the next
 //                segment's first header.  The segment whose walk ended on anything but a plain
 //                block header, or which holds the last value the caller wants, runs to the end of
 //                the page through the checked path, so the tail rules, the status and the consumed
 //                bytes are those of the whole-page decode; the segments behind it do nothing.
-//   3. seg_post_kernel    one lane per page: hands a page some wave gave up on to the sweep
-//                         kernel behind (never seen to happen; the exit every wait must have).
 // A page whose header is unusual in any way is decoded whole by its segment 0.
 #include "delta_wave.hpp"
 #include "pq_launch.hpp"
@@ -617,8 +616,14 @@ __global__ __launch_bounds__(kWG) void seg_fused_kernel(const pq_page_desc *__re
             if (in.status != kInOk) {
                 if (lane == 0) {
                     if (in.status == kInGaveUp) {
+                        // The page goes to the sweep kernel behind this one, whole.  Every segment behind
+                        // this one gives up too, so no wave reaches the page's end and writes over the mark;
+                        // when it is a segment behind the page's last value that gave up, the page is
+                        // complete either way and whichever write comes last is right.
                         look_show_gave_up(L + s);
                         __hip_atomic_store(&pages[pi].giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        results[pg.desc].status = kNeedGeneric;
+                        *flag = epoch;
                     } else {
                         look_show_place(L + s, 0ull, 0ull, kSegNone, kSegNone, 0u);
                     }
@@ -683,18 +688,6 @@ __global__ __launch_bounds__(kWG) void seg_fused_kernel(const pq_page_desc *__re
     }
 }
 
-// ---- 3. pages a wave gave up on -----------------------------------------------------------------------
-
-__global__ __launch_bounds__(kWave) void seg_post_kernel(const SegPage *__restrict__ pages, uint32_t n_pages,
-                                                         pq_page_result *__restrict__ results, uint32_t *flag,
-                                                         uint32_t epoch)
-{
-    const uint32_t i = blockIdx.x * kWave + threadIdx.x;
-    if (i >= n_pages || pages[i].giveup == 0u) return;
-    results[pages[i].desc].status = kNeedGeneric;  // the sweep kernel decodes the page whole
-    *flag = epoch;
-}
-
 hipError_t launch_seg_delta(hipStream_t s, int bits, const pq_page_desc *d_descs, SegPage *d_pages, uint32_t n_pages,
                             const uint32_t *d_owner, uint32_t n_segs, SegRec *d_recs, SegLook *d_looks, PageBuffers buf,
                             pq_page_result *d_results, uint32_t *d_flag, uint32_t epoch, uint32_t spin_limit)
@@ -702,7 +695,7 @@ hipError_t launch_seg_delta(hipStream_t s, int bits, const pq_page_desc *d_descs
     if (n_pages == 0 || n_segs == 0) return hipSuccess;
     const uint32_t per = kWG / kWave;
     const uint32_t n_look16 = n_segs * (uint32_t)(sizeof(SegLook) / 16);
-    const dim3 gp((n_pages + kWave - 1) / kWave), gs((n_segs + per - 1) / per), gh((max(n_pages, n_look16) + kWave - 1) / kWave);
+    const dim3 gs((n_segs + per - 1) / per), gh((max(n_pages, n_look16) + kWave - 1) / kWave);
     uint4 *looks16 = reinterpret_cast<uint4 *>(d_looks);
     if (bits == 64) {
         hipLaunchKernelGGL(seg_header_kernel<uint64_t>, gh, dim3(kWave), 0, s, d_descs, d_pages, n_pages, buf, looks16, n_look16);
@@ -713,7 +706,6 @@ hipError_t launch_seg_delta(hipStream_t s, int bits, const pq_page_desc *d_descs
         hipLaunchKernelGGL(seg_fused_kernel<uint32_t>, gs, dim3(kWG), 0, s, d_descs, d_pages, d_owner, n_segs, d_recs, d_looks,
                            buf, d_results, d_flag, epoch, spin_limit);
     }
-    hipLaunchKernelGGL(seg_post_kernel, gp, dim3(kWave), 0, s, d_pages, n_pages, d_results, d_flag, epoch);
     return hipGetLastError();
 }
 

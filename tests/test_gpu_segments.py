@@ -233,6 +233,42 @@ def test_blocks_of_mixed_widths_and_long_minimums(ctx, bits):
     _run(ctx, cases, bits, 4096, seed=18)
 
 
+def test_block_minimums_of_every_varint_length(ctx):
+    """INT64 blocks whose minDelta zig-zag varint takes one to ten bytes, either sign, from block to block inside
+    one page (a column of nanosecond timestamps is five bytes a block): decoded by the block loops themselves, and
+    stepped over when the page is cut into segments.  Cut streams too: the failing byte may lie in a long varint."""
+    rng = np.random.default_rng(4242)
+    mags = [0, 5, 1 << 6, 1 << 13, 1 << 20, (1 << 27) - 1, 1 << 27, 10**9, 1 << 34, 1 << 41, 1 << 48, 1 << 55, 1 << 61,
+            (1 << 62) + 12345]
+    cases = []
+    for n, block in ((3000, 128), (40_000, 128), (300_000, 128), (3000, 256), (300_000, 256)):
+        nd = n - 1
+        deltas = np.zeros(nd, dtype=np.int64)
+        for b0 in range(0, nd, block):
+            md = int(rng.choice(mags)) * int(rng.choice([1, -1]))
+            if md > 2**31 - 1:
+                md = -md    # the writers start a block's minimum at MaxInt32: larger ones only come negative
+            k = min(block, nd - b0)
+            noise = rng.integers(0, 1 << int(rng.choice([0, 3, 11, 16, 25, 32])), size=k, dtype=np.int64)
+            noise[0] = 0
+            with np.errstate(over="ignore"):
+                deltas[b0:b0 + k] = np.int64(md) + noise
+        with np.errstate(over="ignore"):
+            vals = np.cumsum(np.concatenate([[int(rng.integers(-2**40, 2**40))], deltas])).astype(np.int64)
+        if True:
+            stream = synth.delta_encode(vals, 64, block, 4)
+            want = O.delta_decode64(stream, n)
+            assert want["status"] == O.OK and np.array_equal(want["values"], vals)
+            cases.append(_case(64, stream, n))
+            cases.append(_case(64, stream, n // 2 + 1))
+            for cut in rng.integers(stream.size // 3, stream.size, size=6):
+                c = Case(K.KIND_DELTA64, stream[: int(cut)].copy(), n)
+                c.result_src_len = int(cut)
+                cases.append(c)
+    _run(ctx, cases, 64, 2048, seed=31)
+    _run(ctx, cases, 64, 16384, seed=32)
+
+
 def test_large_and_small_pages_in_one_plan(ctx):
     rng = np.random.default_rng(9)
     cases = []

@@ -437,9 +437,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--pages", type=int, default=2000)
+    ap.add_argument("--seg-bytes", type=int, default=0, help="PQ_OPT_SEGMENT_BYTES for every plan (0: the library chooses)")
     args = ap.parse_args()
     stream = torch.cuda.Stream(device=DEV)
     ctx = capi.Context(0, stream.cuda_stream)
+    if args.seg_bytes:
+        ctx.set_option(capi.OPT_SEGMENT_BYTES, args.seg_bytes)
     want = lambda k: (not args.only) or k in args.only.split(",")
     t0 = time.time()
     if want("c1"):
