@@ -534,6 +534,17 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
     // streams they are
     std::vector<pq_page_desc> descs(user_descs, user_descs + n_pages);
     std::vector<uint32_t> lowered, set_of(n_sets > 1 ? n_pages : 0);
+    // Turning a flat page into its value stream pays where the stream's group is small enough to
+    // have its large pages cut into segments; in a plan of thousands of pages everything a page
+    // kernel can take stays in that one launch, where streams that are bound by memory and streams
+    // that are bound by instruction issue run side by side.
+    size_t in_group[kGroups] = {0};
+    for (size_t i = 0; i < n_pages; ++i) {
+        pq_page_desc t = user_descs[i];
+        if (kind_group(t.kind) < 0) continue;  // refused below
+        (void)lower_flat_page(t);
+        in_group[group_of(t)] += 1;
+    }
     size_t set = 0;
     for (size_t i = 0; i < n_pages; ++i) {
         const pq_page_desc &d = user_descs[i];
@@ -564,9 +575,13 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
             need.dict = std::max(need.dict, d.dict_off + db);
             if (db <= pq::kDictLdsMax) dict_bytes_max = std::max(dict_bytes_max, db);
         }
-        if (lower_flat_page(descs[i])) {
-            lowered.push_back((uint32_t)i);
-            if (!no_levels) plan->lowered_levels = true;
+        {
+            pq_page_desc t = descs[i];
+            if (lower_flat_page(t) && in_group[group_of(t)] < ctx->seg_max_pages) {
+                descs[i] = t;
+                lowered.push_back((uint32_t)i);
+                if (!no_levels) plan->lowered_levels = true;
+            }
         }
         const pq_page_desc &t = descs[i];
         ids[group_of(t)].push_back((uint32_t)i);

@@ -24,6 +24,11 @@ if os.path.exists(sha_file):
 elif RND != "r02":
     sys.exit("no library.sha256 among the results: not collected by tools/profile_%s.sh" % RND)
 os.makedirs(dst, exist_ok=True)
+c3 = src + "_c3"
+if os.path.isdir(c3):  # the all-width sweep, taken in a call of its own
+    if open(os.path.join(c3, "library.sha256")).read().strip() != sha:
+        sys.exit("the width sweep was taken on another build of the library: take it again")
+    shutil.copy(os.path.join(c3, "c3_sweep.jsonl"), os.path.join(src, "c3_sweep.jsonl"))
 for name in sorted(os.listdir(src)):
     p = os.path.join(src, name)
     if os.path.isfile(p) and not name.endswith((".err", ".log")):
