@@ -116,9 +116,14 @@ int pq_ctx_synchronize(pq_ctx *ctx);
  * varint bytes and more: INT64 columns that grow by 2^27 and more a value, at about half the rate
  * of shorter ones); in INT32 columns and in blocks of 256 values only up to four bytes.  Data pages of flat columns (PQ_KIND_PAGE_V1/_V2 with
  * max_rep == 0, max_def == 0) are cut like the bare streams of their value encoding.
- * Dictionary-index pages (PQ_KIND_DICT) and raw hybrid streams (PQ_KIND_HYBRID without flags)
- * whose runs are bit-packed runs of one repeated length (encoding/hybrid-decoder.go:111-136) are cut
- * the same way under the same option.  Default 1024; 0 = never.  Results are the same either way.
+ * Hybrid streams (encoding/hybrid-decoder.go:70-170) are cut under the same option: dictionary-index
+ * pages (PQ_KIND_DICT), raw streams (PQ_KIND_HYBRID), level streams (PQ_KIND_LEVELS) and BOOLEAN RLE
+ * values, whether their runs are bit-packed runs of one repeated length or runs of any kind (then
+ * in segments of about 8192 values).  Data pages of nested columns (max_rep != 0) with 65 536
+ * slots and more run as three such units, repetition levels, definition levels and values, which
+ * the V1 length prefixes and V2 header lengths tell apart before anything is decoded
+ * (layout/page-v1.go:69-77, layout/page-v2.go:110-126).  Default 1024; 0 = never.  Results are the
+ * same either way.
  * PQ_OPT_SEGMENT_BYTES: bytes of the stream per segment, a multiple of 16 from 2048 on; 0 (the
  * default) = chosen from the plan's size, 8 to 64 KiB.  Pages shorter than three segments are not
  * cut.  Both options apply to plans created after the call. */
