@@ -31,6 +31,8 @@ enum DnReason : uint32_t {
 };
 
 constexpr uint32_t kDnOdd = 0xffffffffu;
+// runs in a span of 64 bytes from which on the chain of headers is followed by pointer doubling
+constexpr uint32_t kDnDenseRuns = 16;
 // bit address of the first of the two words that hold RLE values of carried-over runs
 constexpr uint32_t kDnConstBit = (uint32_t)(kHwChunk + 4 * kHwSlack) * 8u;
 // highest bit address a position outside the tile is clamped to
@@ -55,9 +57,10 @@ struct DnNext {
 // append the leading runs that lie wholly in the window and fit `room` values to the tile (each by
 // its own lane), describe what follows in nx.  Returns the number of runs appended, kDnOdd when the
 // header at o itself is not a simple one.
+// dense: the span in front of this one held many runs (in/out; see kDnDenseRuns).
 __device__ __forceinline__ uint32_t dn_span(HybridWaveLds &L, uint32_t o, uint32_t wl, const HwConst &hc, uint32_t room,
                                             uint32_t np, uint32_t fill, uint32_t phase, int lane, uint32_t &values,
-                                            DnNext &nx)
+                                            DnNext &nx, bool &dense)
 {
     const uint32_t p = o + (uint32_t)lane;
     const uint32_t i = p >> 2, sh = (p & 3u) * 8u;
@@ -78,10 +81,36 @@ __device__ __forceinline__ uint32_t dn_span(HybridWaveLds &L, uint32_t o, uint32
     const uint32_t nextlane = (uint32_t)lane + hdr + body;
     const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
 
-    // five scalar instructions between the v_readlane that writes `cur` and the one that uses it as
-    // its lane select cover the wait states that dependency needs
     uint32_t cur;
     uint64_t chain;
+    if (dense) {
+        // Many short runs (RLE-dense streams: a run every three bytes): the chain by pointer doubling
+        // on the vector unit instead of a step per run.  Lane l keeps the set of byte positions the
+        // chain from l visits in 2^k steps and where it stands after them; five rounds cover the 32
+        // runs a span can hold at most (a run is two bytes or more).  ~60 instructions whatever the
+        // number of runs, against six a run below.
+        uint32_t J = ok ? min(nextlane, 64u) : 64u;  // 64: the chain from here has left the span or met no header
+        uint32_t mlo = lane < 32 ? 1u << lane : 0u, mhi = lane < 32 ? 0u : 1u << (lane - 32);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int at = (int)(J << 2);
+            const uint32_t glo = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)mlo);
+            const uint32_t ghi = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)mhi);
+            const uint32_t gj = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)J);
+            const bool on = J < 64u;
+            mlo |= on ? glo : 0u;
+            mhi |= on ? ghi : 0u;
+            J = on ? gj : 64u;
+        }
+        const uint64_t visited = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)mhi) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)mlo);
+        // the walk ends on a byte that is no header (it is visited, not on the chain), or behind the span
+        const uint32_t last = 63u - (uint32_t)__builtin_clzll(visited);
+        chain = visited & okmask;
+        cur = ((okmask >> last) & 1ull) != 0ull ? (uint32_t)__builtin_amdgcn_readlane((int)nextlane, (int)last) : last;
+    } else {
+    // five scalar instructions between the v_readlane that writes `cur` and the one that uses it as
+    // its lane select cover the wait states that dependency needs
     asm volatile("s_mov_b64 %[chain], 0\n\t"
                  "s_mov_b32 %[cur], 0\n"
                  "1:\n\t"
@@ -95,6 +124,8 @@ __device__ __forceinline__ uint32_t dn_span(HybridWaveLds &L, uint32_t o, uint32
                  : [chain] "=&s"(chain), [cur] "=&s"(cur)
                  : [ok] "s"(okmask), [next] "v"(nextlane)
                  : "scc");
+    }
+    dense = hc.w != 0u && (uint32_t)__builtin_popcountll(chain) >= kDnDenseRuns;
     values = 0;
     nx.kind = 0;
     nx.count = 0;
@@ -271,6 +302,7 @@ __device__ __forceinline__ uint32_t hw_dense_tiles(HybridWaveLds &L, HwState &st
     uint32_t cur_phase = 4;  // none yet
     uint32_t posv[Q][4];
     uint32_t cslot = 0;
+    bool dense = false;  // what the last span said of the stream
     for (;;) {
         if (st.v >= n) return DN_DONE;
         const uint32_t phase = (st.v + mis) & 3u;
@@ -340,7 +372,7 @@ __device__ __forceinline__ uint32_t hw_dense_tiles(HybridWaveLds &L, HwState &st
                 if (st.o >= wl) { reason = DN_GENERIC; break; }
                 uint32_t values;
                 DnNext nx;
-                const uint32_t taken = dn_span(L, st.o, wl, hc, want - fill, np, fill, phase, lane, values, nx);
+                const uint32_t taken = dn_span(L, st.o, wl, hc, want - fill, np, fill, phase, lane, values, nx, dense);
                 if (taken == kDnOdd) { reason = DN_GENERIC; break; }
                 np += taken;
                 fill += values;
