@@ -558,3 +558,76 @@ def test_run_streams_in_segments_vs_oracle(ctx, seg_bytes):
     finally:
         ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 1024)
         ctx.set_option(K.OPT_SEGMENT_BYTES, 0)
+
+
+def _hand_runs(rng, w, n_runs, rle_share, kinds=("rle8", "bp1")):
+    """A hybrid stream put together run by run, with runs no encoder would close so early: RLE runs of 1..40
+    repeats and bit-packed runs of 1..3 groups, so that a span of 64 bytes holds up to 32 run headers."""
+    vb = (w + 7) // 8
+    parts, values = [], []
+    for _ in range(n_runs):
+        if rng.random() < rle_share:
+            cnt = int(rng.integers(1, 41))
+            v = int(rng.integers(0, 1 << w))
+            parts.append(np.array([cnt << 1], dtype=np.uint8))
+            parts.append(np.frombuffer(int(v).to_bytes(vb, "little"), dtype=np.uint8))
+            values.append(np.full(cnt, v, dtype=np.int64))
+        else:
+            g = int(rng.integers(1, 4))
+            vals = rng.integers(0, 1 << w, size=8 * g, dtype=np.int64)
+            parts.append(np.array([(g << 1) | 1], dtype=np.uint8))
+            parts.append(synth.pack_bits(vals, w))
+            values.append(vals)
+    return np.concatenate(parts).astype(np.uint8), np.concatenate(values)
+
+
+def test_spans_of_many_short_runs(ctx):
+    """Streams whose runs are two or three bytes each: a span of 64 header bytes holds 16 to 32 of them, which is
+    where the tiles follow the chain of run headers by pointer doubling instead of a step per run.  Whole streams,
+    streams pulled short, cut streams, an RLE value too large for the width in the middle; small pages (one wave
+    a stream) and the same cut into segments."""
+    rng = np.random.default_rng(77001)
+    cases = []
+
+    def add(tag, kind, stream, n, **kw):
+        c = Case(kind, stream, n, **kw)
+        c.result_src_len = c.src.size
+        c.tag = tag
+        cases.append(c)
+
+    for w in (1, 2, 3, 7, 8, 9, 12, 16):
+        for share in (1.0, 0.85, 0.5):
+            s, vals = _hand_runs(rng, w, 6000, share)
+            n = vals.size
+            st, want, _ = O.hybrid_decode(s, w, n, False)
+            assert st == O.OK and np.array_equal(want, vals)
+            add("hybrid w %d share %.2f" % (w, share), K.KIND_HYBRID, s, n, bit_width=w)
+            add("hybrid w %d share %.2f pull" % (w, share), K.KIND_HYBRID, s, n // 2 + 5, bit_width=w)
+            for cut in rng.integers(s.size // 4, s.size, size=3):
+                add("hybrid w %d share %.2f cut %d" % (w, share, cut), K.KIND_HYBRID, s[: int(cut)].copy(), n, bit_width=w)
+            if w < 8:
+                bad = s.copy()      # the value byte of an RLE run somewhere in the middle gets a bit above the width
+                at = int(np.flatnonzero((bad[: bad.size // 2] & 1) == 0)[-1]) + 1
+                bad[at] |= 0x80
+                add("hybrid w %d share %.2f bad value" % (w, share), K.KIND_HYBRID, bad, n, bit_width=w)
+    for max_level in (1, 3):
+        w = int(max_level).bit_length()
+        s, vals = _hand_runs(rng, w, 20000, 0.9)
+        vals = np.minimum(vals, max_level)
+        s2, _ = s, None
+        add("levels max %d hand runs" % max_level, K.KIND_LEVELS, s, vals.size, max_def=max_level)
+        add("levels max %d hand runs cut" % max_level, K.KIND_LEVELS, s[: s.size * 2 // 3].copy(), vals.size,
+            max_def=max_level)
+    s, vals = _hand_runs(rng, 1, 30000, 0.95)
+    add("bool rle hand runs", K.KIND_BOOL_RLE, synth.length_prefixed(s), vals.size)
+    try:
+        for max_pages, sb in ((0, 0), (1 << 30, 2048)):
+            ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, max_pages)
+            ctx.set_option(K.OPT_SEGMENT_BYTES, sb)
+            run_cases(ctx, cases, seed=5)
+            for c in cases:
+                _check_run_stream(c)
+    finally:
+        ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 1024)
+        ctx.set_option(K.OPT_SEGMENT_BYTES, 0)
+
