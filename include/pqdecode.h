@@ -138,6 +138,13 @@ int pq_ctx_synchronize(pq_ctx *ctx);
  * workgroups start in the order of their index); 0 = a wave that would have to wait gives up at once,
  * which is how the tests reach that path.  Results are the same either way. */
 #define PQ_OPT_SEGMENT_SPIN_LIMIT 6
+/* PQ_OPT_CONCURRENT_GROUPS: a plan decodes its descriptors in groups, one kernel each (streams, delta
+ * pages, whole data pages, byte arrays).  With 1 (the default) a plan in which at least two of them
+ * have 16 MiB and more to move runs them side by side on streams of the library's own, forked from
+ * the context's stream and joined to it again before pq_plan_run returns control of that stream to
+ * the work behind it: nothing changes for the caller but the time.  0: one after the other on the
+ * context's stream.  Never used while the context's stream is being captured into a graph. */
+#define PQ_OPT_CONCURRENT_GROUPS 7
 int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value);
 const char *pq_status_string(int status);
 const char *pq_last_error(pq_ctx *ctx); /* text of the last HIP failure on ctx */

@@ -53,6 +53,11 @@ struct pq_ctx {
     // all copies to the device go through one stream and all copies back through another, so that
     // each direction's copies queue up behind one another without gaps
     hipStream_t chunk_in = nullptr, chunk_out = nullptr;
+    // plans whose groups are large enough run them side by side: up to three streams next to the
+    // context's own, forked from it and joined to it with events (PQ_OPT_CONCURRENT_GROUPS)
+    bool concurrent_groups = true;
+    hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t lane_fork = nullptr, lane_join[3] = {nullptr, nullptr, nullptr};
 };
 
 constexpr int kChunkSlotsMax = 8;
@@ -89,6 +94,10 @@ struct pq_plan {
     uint32_t first[kGroups] = {0, 0, 0, 0, 0, 0, 0};
     uint32_t dict_lds_bytes = 0;  // the largest dictionary that fits LDS: what a workgroup sets aside for its copy
     bool has_delta_page = false; // some PAGE_V1/V2 descriptor carries delta values
+    // bytes in and out of the four lanes a run may work side by side: streams | delta pages | data
+    // pages | byte arrays; `fork`: at least two of them are worth a stream of their own
+    uint64_t lane_work[4] = {0, 0, 0, 0};
+    bool fork = false;
     // delta32 / delta64 descriptors that are decoded in segments: the last n_seg_pages[k] ids of
     // group 1 + k, their page records, the segment -> page map and the segment records
     uint32_t n_seg_pages[2] = {0, 0};
@@ -207,7 +216,8 @@ uint32_t value_size(const pq_page_desc &d)
 // (max_def != 0: the constant level 0 never equals it), empty pages and V2 pages whose level bytes
 // are not all there stay with the page kernels.
 constexpr uint64_t kSegValues = 8192;        // values a segment of a run-dense hybrid stream aims at
-constexpr uint32_t kNestedSplitMin = 65536;  // level slots from which a nested page is worth three units
+constexpr uint32_t kNestedSplitMin = 65536;
+constexpr uint64_t kForkMinBytes = 16ull << 20;  // a lane of a plan with less to move than this is not worth a fork  // level slots from which a nested page is worth three units
 constexpr uint32_t kFlagLowered = 0x80000000u;  // internal: never set by callers (validate refuses it)
 
 bool lower_flat_page(pq_page_desc &d)
@@ -396,6 +406,14 @@ void pq_ctx_destroy(pq_ctx *ctx)
         (void)hipSetDevice(ctx->device);
     }
     if (ctx->spare_block) (void)hipFree(ctx->spare_block);
+    for (int i = 0; i < 3; ++i) {
+        if (ctx->lane_stream[i]) {
+            (void)hipStreamSynchronize(ctx->lane_stream[i]);
+            (void)hipStreamDestroy(ctx->lane_stream[i]);
+        }
+        if (ctx->lane_join[i]) (void)hipEventDestroy(ctx->lane_join[i]);
+    }
+    if (ctx->lane_fork) (void)hipEventDestroy(ctx->lane_fork);
     for (int i = 0; i < 2; ++i) {
         if (ctx->host_img[i]) (void)hipHostFree(ctx->host_img[i]);
         if (ctx->host_img_done[i]) (void)hipEventDestroy(ctx->host_img_done[i]);
@@ -436,6 +454,10 @@ int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value)
         // a segment holds at least one block header (a 256-value block is at most 1038 bytes)
         if (value != 0 && (value < 2048 || value > (1ll << 24) || (value & 15) != 0)) return PQ_ERR_BAD_ARGUMENT;
         ctx->seg_bytes = (uint32_t)value;
+        return PQ_OK;
+    case PQ_OPT_CONCURRENT_GROUPS:
+        if (value != 0 && value != 1) return PQ_ERR_BAD_ARGUMENT;
+        ctx->concurrent_groups = value != 0;
         return PQ_OK;
     case PQ_OPT_SEGMENT_SPIN_LIMIT:
         if (value < 0) return PQ_ERR_BAD_ARGUMENT;
@@ -585,11 +607,21 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
         }
         const pq_page_desc &t = descs[i];
         ids[group_of(t)].push_back((uint32_t)i);
+        {
+            static const int lane_of[kGroups] = {0, 1, 1, 2, 3, 3, 0};
+            const uint32_t out = vs ? vs : 4u;
+            plan->lane_work[lane_of[group_of(t)]] += t.src_len + (uint64_t)t.n_values * out;
+        }
         if ((t.kind == PQ_KIND_PAGE_V1 || t.kind == PQ_KIND_PAGE_V2) &&
             (t.value_kind == PQ_KIND_DELTA32 || t.value_kind == PQ_KIND_DELTA64))
             plan->has_delta_page = true;
     }
     plan->n_lowered = (uint32_t)lowered.size();
+    {
+        int big = 0;
+        for (uint64_t w : plan->lane_work) big += w >= kForkMinBytes ? 1 : 0;
+        plan->fork = big >= 2;
+    }
     plan->dict_lds_bytes = (uint32_t)((dict_bytes_max + 15u) & ~15ull);
 
     // Few large pages of nested columns: each becomes three units of work — its repetition levels,
@@ -974,31 +1006,73 @@ static int plan_launch(pq_plan *plan, pq::PageBuffers buf)
                                             plan->d_results, 0, wl, plan->hs[1].d_pages, plan->hs[1].n_pages));
         PQ_HIP(ctx, pq::launch_nested_values(ctx->stream, plan->d_descs, plan->d_npages, plan->n_split, plan->d_results));
     }
-    PQ_HIP(ctx, seg_hybrid(plan->hs[0]));
-    PQ_HIP(ctx, pq::launch_stream_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[0], plan->count[0], buf,
+    // The four lanes — streams, delta pages, data pages, byte arrays — share nothing but the
+    // descriptor table they read.  A plan with two lanes and more that are worth it forks them off
+    // the context's stream and joins them again: kernels bound by memory and kernels bound by
+    // instruction issue then run side by side instead of each waiting for the other's last wave.
+    // Not under stream capture (what a capture makes of side streams is the caller's design).
+    bool fork = plan->fork && ctx->concurrent_groups;
+    if (fork) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        PQ_HIP(ctx, hipStreamIsCapturing(ctx->stream, &cs));
+        fork = cs == hipStreamCaptureStatusNone;
+    }
+    hipStream_t lane[4] = {ctx->stream, ctx->stream, ctx->stream, ctx->stream};
+    if (fork) {
+        if (!ctx->lane_fork) PQ_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_fork, hipEventDisableTiming));
+        PQ_HIP(ctx, hipEventRecord(ctx->lane_fork, ctx->stream));
+        int used = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (plan->lane_work[k] == 0) continue;
+            if (used++ == 0) continue;  // the first lane with work stays on the context's stream
+            const int i = used - 2;
+            if (!ctx->lane_stream[i]) {
+                PQ_HIP(ctx, hipStreamCreateWithFlags(&ctx->lane_stream[i], hipStreamNonBlocking));
+                PQ_HIP(ctx, hipEventCreateWithFlags(&ctx->lane_join[i], hipEventDisableTiming));
+            }
+            lane[k] = ctx->lane_stream[i];
+            PQ_HIP(ctx, hipStreamWaitEvent(lane[k], ctx->lane_fork, 0));
+        }
+    }
+    auto seg_hybrid0 = [&](hipStream_t st) {
+        const pq_plan::HsegDev &hd = plan->hs[0];
+        return pq::launch_seg_hybrid(st, plan->d_descs, hd.d_pages, hd.n_pages, hd.d_check_owner, hd.n_checks, hd.d_counts,
+                                     hd.d_seg_owner, hd.n_segs, hd.d_recs, hd.d_scans, buf, plan->d_results,
+                                     plan->dict_lds_bytes);
+    };
+    PQ_HIP(ctx, seg_hybrid0(lane[0]));
+    PQ_HIP(ctx, pq::launch_stream_pages(lane[0], plan->d_descs, plan->d_ids + plan->first[0], plan->count[0], buf,
                                         plan->d_results, plan->dict_lds_bytes, wl, plan->hs[0].d_pages,
                                         plan->hs[0].n_pages));
     plan->epoch += 1;
     if (plan->epoch == 0) plan->epoch = 1; // 0 is what the flag words start as
     bool serial32 = false, serial64 = false;
     for (int k = 0; k < 2; ++k)  // the pages cut into segments first: they are the long ones
-        PQ_HIP(ctx, pq::launch_seg_delta(ctx->stream, k ? 64 : 32, plan->d_descs, plan->d_seg_pages[k],
+        PQ_HIP(ctx, pq::launch_seg_delta(lane[1], k ? 64 : 32, plan->d_descs, plan->d_seg_pages[k],
                                          plan->n_seg_pages[k], plan->d_seg_owner[k], plan->n_segs[k],
                                          plan->d_seg_recs[k], plan->d_seg_looks[k], buf, plan->d_results,
                                          plan->d_flags + 32 * k, plan->epoch, ctx->seg_spin_limit));
-    PQ_HIP(ctx, pq::launch_delta_pages(ctx->stream, 32, plan->d_descs, plan->d_ids + plan->first[1],
+    PQ_HIP(ctx, pq::launch_delta_pages(lane[1], 32, plan->d_descs, plan->d_ids + plan->first[1],
                                        plan->count[1] - plan->n_seg_pages[0], plan->count[1], buf, plan->d_results,
                                        ctx->delta_wave_min_pages, plan->d_flags, plan->epoch, &serial32));
-    PQ_HIP(ctx, pq::launch_delta_pages(ctx->stream, 64, plan->d_descs, plan->d_ids + plan->first[2],
+    PQ_HIP(ctx, pq::launch_delta_pages(lane[1], 64, plan->d_descs, plan->d_ids + plan->first[2],
                                        plan->count[2] - plan->n_seg_pages[1], plan->count[2], buf, plan->d_results,
                                        ctx->delta_wave_min_pages, plan->d_flags + 32, plan->epoch, &serial64));
-    PQ_HIP(ctx, pq::launch_data_pages(ctx->stream, plan->d_descs, plan->d_ids + plan->first[3],
+    PQ_HIP(ctx, pq::launch_data_pages(lane[2], plan->d_descs, plan->d_ids + plan->first[3],
                                       plan->count[3], buf, plan->d_results, plan->dict_lds_bytes, wl,
                                       plan->d_flags + 64, plan->epoch));
-    PQ_HIP(ctx, pq::launch_byte_arrays(ctx->stream, PQ_KIND_DELTA_LENGTH_BA, plan->d_descs, plan->d_ids + plan->first[4],
+    PQ_HIP(ctx, pq::launch_byte_arrays(lane[3], PQ_KIND_DELTA_LENGTH_BA, plan->d_descs, plan->d_ids + plan->first[4],
                                        plan->count[4], buf, plan->d_results));
-    PQ_HIP(ctx, pq::launch_byte_arrays(ctx->stream, PQ_KIND_DELTA_BA, plan->d_descs, plan->d_ids + plan->first[5],
+    PQ_HIP(ctx, pq::launch_byte_arrays(lane[3], PQ_KIND_DELTA_BA, plan->d_descs, plan->d_ids + plan->first[5],
                                        plan->count[5], buf, plan->d_results));
+    if (fork)
+        for (int i = 0; i < 3; ++i) {
+            bool in_use = false;
+            for (int k = 0; k < 4; ++k) in_use = in_use || lane[k] == ctx->lane_stream[i];
+            if (!in_use || !ctx->lane_stream[i]) continue;
+            PQ_HIP(ctx, hipEventRecord(ctx->lane_join[i], ctx->lane_stream[i]));
+            PQ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_join[i], 0));
+        }
     // groups 1..3 are contiguous in d_ids; pages whose delta layout the tiled kernels
     // declined (and did not finish themselves) are completed one lane per page
     if (serial32 || serial64 || plan->has_delta_page)

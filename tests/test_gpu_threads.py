@@ -179,3 +179,22 @@ def test_four_threads_four_contexts_and_one_that_churns():
     churn.join(timeout=60)
     assert not any(t.is_alive() for t in workers) and not churn.is_alive(), "a thread did not finish"
     assert not errors, errors
+
+
+def test_groups_of_a_large_plan_side_by_side_and_one_after_the_other():
+    """A plan whose delta pages, dictionary pages and nested data pages each have 16 MiB and more to move runs those
+    groups on streams of the library's own, forked from the context's stream and joined to it again
+    (PQ_OPT_CONCURRENT_GROUPS, on by default); the same plan with the option off runs them one after the other.
+    Every page of both against the oracle, three runs each way (a second run must not see the first one's state)."""
+    rng = np.random.default_rng(31337)
+    wl = _pages_workload(rng, 1500)
+    ctx = capi.Context(0)
+    try:
+        for on in (1, 0, 1):
+            ctx.set_option(K.OPT_CONCURRENT_GROUPS, on)
+            for _ in range(3 if on else 1):
+                res, values, levels = ctx.decode_pages(wl["descs"], wl["src"], wl["values_bytes"], wl["levels_bytes"], wl["dict"])
+                _check_pages(wl, res, values, levels)
+    finally:
+        ctx.close()
+
