@@ -440,16 +440,75 @@ __device__ __forceinline__ void wave_decode_tile(const uint32_t *lds, const Wave
 // pair that is not of that kind, having advanced o (window offset of the next header), p0
 // (position of its first value), carry (that value) and *wo.  stop_rel: a header at or behind
 // this window offset is not to be decoded (segments), else 0x7fffffff.
+// tab / tab_n / ti / tab_md0 / c0: blocks whose headers a walk in front of the decode has parsed
+// (see delta_wave_tiles); pairs of them are taken from there first.
 template <typename UT, bool OFFS>
 __device__ __forceinline__ void delta_pair_loop(const uint32_t *lds, UT *dst, uint32_t &o, uint32_t &p0, UT &carry,
                                                 uint32_t need, uint32_t lim, uint32_t o_max, int32_t stop_rel,
-                                                WaveOffsets *wo, int lane)
+                                                WaveOffsets *wo, int lane, const uint32_t *tab = nullptr,
+                                                uint32_t tab_n = 0, uint32_t tab_p0 = 0, int32_t tab_md0 = 0,
+                                                uint32_t c0 = 0)
 {
     static_assert(sizeof(UT) == 4, "four adjacent values per lane go out in one 16-byte store");
     const bool upper = lane >= 32;
     const uint32_t j = (uint32_t)lane & 31u;
     const uint32_t sh8 = (j >> 3) * 8u;  // 8 * the miniblock of this lane's 4 values
     const uint32_t k4 = 4u * (j & 7u);   // index of the first of them inside the miniblock
+    // the two blocks of a pair behind their headers: widths, window offset of the packed data and
+    // minDelta per half of the wave
+    auto emit_pair = [&](uint32_t widths, uint32_t data, int32_t md) {
+        const uint32_t w = __builtin_amdgcn_ubfe(widths, sh8, 8u);
+        const uint32_t sum2 = widths + (widths << 8);
+        const uint32_t sums = sum2 + (sum2 << 16);
+        const uint32_t pre = __builtin_amdgcn_ubfe(sums << 8, sh8, 8u);
+        const uint32_t bit = data * 8u + (pre << 5) + __umul24(k4, w);
+        const uint32_t m = (uint32_t)(1ull << w) - 1u;  // w == 32 -> 0xffffffff, w == 0 -> 0
+        uint32_t u[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const uint32_t bq = bit + q * w;
+            const uint32_t i = bq >> 5;
+            u[q] = __builtin_amdgcn_alignbit(lds[i + 1], lds[i], bq) & m;
+        }
+        UT v[4];
+        const UT s1 = u[0] + (UT)md, s2 = s1 + u[1] + (UT)md, s3 = s2 + u[2] + (UT)md, s4 = s3 + u[3] + (UT)md;
+        const UT incl = wave_scan_u32(s4);
+        v[0] = carry + (incl - s4);
+        v[1] = v[0] + s1;
+        v[2] = v[0] + s2;
+        v[3] = v[0] + s3;
+        carry += wave_last_u32(incl);
+        if constexpr (OFFS) {
+            // the values are lengths: what is stored is the sum of those in front.  256 lengths
+            // below 2^23 on top of a total below 2^31 cannot wrap.
+            const uint32_t t1 = v[0], t2 = t1 + v[1], t3 = t2 + v[2], t4 = t3 + v[3];
+            const uint32_t oincl = wave_scan_u32(t4);
+            wo->big |= __builtin_amdgcn_ballot_w64((v[0] | v[1] | v[2] | v[3]) >= (1u << 23)) != 0ull ? 1u : 0u;
+            v[0] = wo->sum + (oincl - t4);
+            v[1] = v[0] + t1;
+            v[2] = v[0] + t2;
+            v[3] = v[0] + t3;
+            wo->sum += wave_last_u32(oincl);
+            wo->big |= wo->sum >> 31;
+        }
+        store_nt16(dst + p0 + 4u * (uint32_t)lane, v[0], v[1], v[2], v[3]);
+    };
+    if (tab != nullptr) {
+        // entry i is the block whose first value has position tab_p0 + 128 i: whichever loop took the
+        // blocks in front, the table is read at the block that is next
+        while (((p0 - tab_p0) >> 7) + 1u < tab_n && p0 + 256u < need) {
+            const uint32_t ti = (p0 - tab_p0) >> 7;
+            const uint32_t e = 4u * (ti + (upper ? 1u : 0u));
+            const uint32_t data = tab[e] - c0, widths = tab[e + 1u];
+            const int32_t md = (ti == 0u && !upper) ? tab_md0 : (int32_t)tab[e + 2u];
+            const uint32_t next = data + 4u * __builtin_amdgcn_sad_u8(widths, 0u, 0u);
+            const uint32_t next_b = (uint32_t)__builtin_amdgcn_readlane((int)next, 63);
+            if (next_b > lim) break;  // the pair does not lie wholly in this window
+            emit_pair(widths, data, md);
+            o = next_b;
+            p0 += 256u;
+        }
+    }
     while (o <= o_max && p0 + 256u < need && (int32_t)o < stop_rel) {
         // where the second header starts: the first one's varint length and the sum of its widths
         uint32_t next_a;
@@ -484,44 +543,7 @@ __device__ __forceinline__ void delta_pair_loop(const uint32_t *lds, UT *dst, ui
         const uint32_t mv = hdr_lo & (0xffffffffu >> (32u - 8u * vl));
         const uint32_t mx = (mv & 0x7fu) | ((mv >> 1) & 0x3f80u) | ((mv >> 2) & 0x1fc000u) | ((mv >> 3) & 0xfe00000u);
         const int32_t md = (int32_t)(mx >> 1) ^ -(int32_t)(mx & 1u);
-        // the four deltas: byte m of `sums` = the widths of miniblocks 0..m together (at most 128)
-        const uint32_t w = __builtin_amdgcn_ubfe(widths, sh8, 8u);
-        const uint32_t sum2 = widths + (widths << 8);
-        const uint32_t sums = sum2 + (sum2 << 16);
-        const uint32_t pre = __builtin_amdgcn_ubfe(sums << 8, sh8, 8u);
-        const uint32_t bit = data * 8u + (pre << 5) + __umul24(k4, w);
-        const uint32_t m = (uint32_t)(1ull << w) - 1u;  // w == 32 -> 0xffffffff, w == 0 -> 0
-        uint32_t u[4];
-#pragma unroll
-        for (uint32_t q = 0; q < 4u; ++q) {
-            const uint32_t bq = bit + q * w;
-            const uint32_t i = bq >> 5;
-            u[q] = __builtin_amdgcn_alignbit(lds[i + 1], lds[i], bq) & m;
-        }
-        UT v[4];
-        {
-            const UT s1 = u[0] + (UT)md, s2 = s1 + u[1] + (UT)md, s3 = s2 + u[2] + (UT)md, s4 = s3 + u[3] + (UT)md;
-            const UT incl = wave_scan_u32(s4);
-            v[0] = carry + (incl - s4);
-            v[1] = v[0] + s1;
-            v[2] = v[0] + s2;
-            v[3] = v[0] + s3;
-            carry += wave_last_u32(incl);
-            if constexpr (OFFS) {
-                // the values are lengths: what is stored is the sum of those in front.  256 lengths
-                // below 2^23 on top of a total below 2^31 cannot wrap.
-                const uint32_t t1 = v[0], t2 = t1 + v[1], t3 = t2 + v[2], t4 = t3 + v[3];
-                const uint32_t oincl = wave_scan_u32(t4);
-                wo->big |= __builtin_amdgcn_ballot_w64((v[0] | v[1] | v[2] | v[3]) >= (1u << 23)) != 0ull ? 1u : 0u;
-                v[0] = wo->sum + (oincl - t4);
-                v[1] = v[0] + t1;
-                v[2] = v[0] + t2;
-                v[3] = v[0] + t3;
-                wo->sum += wave_last_u32(oincl);
-                wo->big |= wo->sum >> 31;
-            }
-            store_nt16(dst + p0 + 4u * (uint32_t)lane, v[0], v[1], v[2], v[3]);
-        }
+        emit_pair(widths, data, md);
         o = (uint32_t)__builtin_amdgcn_readlane((int)next, 63);
         p0 += 256u;
     }
@@ -571,13 +593,18 @@ struct WaveDeltaResult {
 // SEG: the decode starts in the middle of the page, at the block header at `pos` whose first value
 // has position seg_p0 (a multiple of the block size) and is `first`, and ends in front of the
 // block header at stream offset seg_stop (status kSegStopped; < 0: runs to the end of the page
-// like the whole-page decode, tail rules, status and consumed bytes included).
+// like the whole-page decode, tail rules, status and consumed bytes included).  tab / tab_n: the
+// segment's first tab_n blocks as the walk in front of the decode found them, four words each —
+// stream offset of the block's packed data, its four width bytes, its minDelta (two words) —
+// so that the decode does not parse their headers again; tab_md0 is the first block's minDelta
+// (the walk may not know it).
 template <typename UT, uint32_t LG, bool OFFS = false, bool SEG = false>
 __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const uint8_t *S, int64_t len, uint32_t n,
                                                             UT *dst, int lane, WavePrefetch &pf, int64_t c0, int64_t pos,
                                                             uint32_t total32, uint64_t first, bool vec_ok,
                                                             WaveOffsets *wo = nullptr, uint32_t seg_p0 = 0,
-                                                            int64_t seg_stop = -1)
+                                                            int64_t seg_stop = -1, const uint32_t *tab = nullptr,
+                                                            uint32_t tab_n = 0, int64_t tab_md0 = 0)
 {
     WaveDeltaResult res{PQ_OK, 0, 0, 0, total32};
     WaveState<UT> st;
@@ -649,7 +676,8 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
                     // pairs of blocks first; what ends the pair loop is one of the single-block loop's cases
                     if (vec16)
                         delta_pair_loop<UT, OFFS>(lds, dst, o, p0, carry, st.need, lim,
-                                                  tail ? 0x7fffffffu : (uint32_t)(kDwChunk - 2 * kDwBlockMax), stop_rel, wo, lane);
+                                                  tail ? 0x7fffffffu : (uint32_t)(kDwChunk - 2 * kDwBlockMax), stop_rel, wo, lane,
+                                                  SEG ? tab : nullptr, tab_n, seg_p0, (int32_t)tab_md0, (uint32_t)c0);
                 }
                 // one block behind its header: widths (a byte per miniblock), window offset of its data, minDelta
                 auto emit_block = [&](uint32_t widths, uint32_t data, int64_t md, uint32_t vl) {
@@ -721,6 +749,22 @@ __device__ __forceinline__ WaveDeltaResult delta_wave_tiles(uint32_t *lds, const
                             }
                         }
                 };
+                if constexpr (SEG && LG == 5u && sizeof(UT) == 8) {
+                    // blocks whose headers the segment's walk has parsed already
+                    // (entry i is the block whose first value has position seg_p0 + 128 i)
+                    while (((p0 - seg_p0) >> 7) < tab_n && p0 + 128u < st.need) {
+                        const uint32_t ti = (p0 - seg_p0) >> 7;
+                        const uint32_t e0 = uni(tab[4u * ti]), e1 = uni(tab[4u * ti + 1u]);
+                        const uint32_t data = e0 - (uint32_t)c0;
+                        const uint32_t next = data + 4u * __builtin_amdgcn_sad_u8(e1, 0u, 0u);
+                        if (next > lim) break;  // not wholly in this window
+                        const int64_t md = ti == 0u ? tab_md0
+                                                    : (int64_t)(((uint64_t)uni(tab[4u * ti + 3u]) << 32) | uni(tab[4u * ti + 2u]));
+                        emit_block(e1, data, md, md >= -(1ll << 20) && md < (1ll << 20) ? 3u : 4u);
+                        o = next;
+                        p0 += 128u;
+                    }
+                }
                 if constexpr (LG == 5u && sizeof(UT) == 8) {
                     // Two blocks an iteration: the lower half of the wave reads the first header, the upper
                     // half the second (which starts where the first says), all in vector registers; what

@@ -42,6 +42,7 @@
 namespace pq {
 
 constexpr uint32_t kSegNone = 0xffffffffu;
+constexpr uint32_t kSegTab = 128;  // blocks of a segment whose headers the decode takes from the walk
 
 // ---- 1. stream headers ----------------------------------------------------------------------
 
@@ -146,11 +147,14 @@ __device__ __forceinline__ SegCand seg_parse(const uint32_t *lds, uint32_t wo, u
 
 // forced != kSegNone: no guess, the first block's width bytes are known to be at `forced`.
 template <uint32_t LG>
+// tab (kSegTab entries of four words) / tab_n: the blocks walked, for the decode (delta_wave_tiles).
 __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int64_t len, uint32_t s, uint32_t seg_bytes,
-                                            uint32_t pos0, int lane, uint32_t forced = kSegNone)
+                                            uint32_t pos0, int lane, uint32_t *tab, uint32_t &tab_n,
+                                            uint32_t forced = kSegNone)
 {
     constexpr uint32_t kBlockMax = LG == 5u ? 544u : 1040u;  // >= the longest block, a multiple of 16
     const int64_t lo = (int64_t)s * seg_bytes, hi = lo + seg_bytes;
+    tab_n = 0;
     WavePrefetch pf;
     int64_t c0 = chunk_base(S, s == 0u ? 0 : (forced != kSegNone ? (int64_t)forced - 1 : lo - 1));
     wave_fetch(pf, S, c0, len, lane);
@@ -260,7 +264,15 @@ __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int
                     if (__builtin_amdgcn_ballot_w64(pbad) != 0ull) break;
                     const uint32_t mv = h_lo & (0xffffffffu >> (32u - 8u * vlp));
                     const uint32_t mx = (mv & 0x7fu) | ((mv >> 1) & 0x3f80u) | ((mv >> 2) & 0x1fc000u) | ((mv >> 3) & 0xfe00000u);
-                    const int32_t mdp = ((int32_t)(mx >> 1) ^ -(int32_t)(mx & 1u)) & (int32_t)(upper ? 0xffffffffu : md_mask);
+                    const int32_t md_raw = (int32_t)(mx >> 1) ^ -(int32_t)(mx & 1u);
+                    if (j == 0u && nblk + 1u < kSegTab) {  // lanes 0 and 32: this pair's two entries
+                        const uint32_t e = 4u * (nblk + (upper ? 1u : 0u));
+                        tab[e] = (uint32_t)c0 + data;
+                        tab[e + 1u] = widths;
+                        tab[e + 2u] = (uint32_t)md_raw;
+                        tab[e + 3u] = (uint32_t)(md_raw >> 31);
+                    }
+                    const int32_t mdp = md_raw & (int32_t)(upper ? 0xffffffffu : md_mask);
                     const uint32_t w = __builtin_amdgcn_ubfe(widths, sh8p, 8u);
                     const uint32_t sum2 = widths + (widths << 8);
                     const uint32_t sums = sum2 + (sum2 << 16);
@@ -276,6 +288,7 @@ __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int
                     }
                     acc += four;
                     md_mask = 0xffffffffu;
+                    if (nblk + 1u < kSegTab) tab_n = nblk + 2u;
                     nblk += 2u;
                     o = (uint32_t)__builtin_amdgcn_readlane((int)next, 63);
                 }
@@ -313,6 +326,16 @@ __device__ __forceinline__ SegScan seg_scan(uint32_t *lds, const uint8_t *S, int
                 // minDelta twice per lane (its two values), expanded on the vector unit like the decode does
                 const int64_t md = md_mask == 0u ? 0ll : (lng ? md_long : (int64_t)wave_expand_min_delta(hdr_lo, vl));
                 acc += (uint64_t)ua + (uint64_t)ub + 2ull * (uint64_t)md;
+                if (nblk < kSegTab && tab_n == nblk) {  // the table has no gaps: it ends where one block was not recorded
+                    const int64_t mr = lng ? md_long : wave_raw_min_delta(hdr_lo, vl);
+                    if (lane == 0) {
+                        tab[4u * nblk] = (uint32_t)c0 + data;
+                        tab[4u * nblk + 1u] = widths;
+                        tab[4u * nblk + 2u] = (uint32_t)mr;
+                        tab[4u * nblk + 3u] = (uint32_t)((uint64_t)mr >> 32);
+                    }
+                    tab_n = nblk + 1u;
+                }
                 md_mask = 0xffffffffu;
                 nblk += 1u;
                 o = next;
@@ -574,10 +597,13 @@ __global__ __launch_bounds__(kWG) void seg_fused_kernel(const pq_page_desc *__re
                                                         uint32_t epoch, uint32_t spin_limit)
 {
     __shared__ __attribute__((aligned(16))) uint32_t window[kWG / kWave][kDwChunk / 4 + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t blocks[kWG / kWave][4 * kSegTab];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t g = blockIdx.x * (kWG / kWave) + (uint32_t)wave;
     if (g >= n_segs) return;
+    uint32_t *tab = blocks[wave];
+    uint32_t tab_n = 0;
     const uint32_t pi = owner[g];
     const SegPage pg = pages[pi];
     const uint32_t s = g - pg.seg_first;
@@ -604,10 +630,11 @@ __global__ __launch_bounds__(kWG) void seg_fused_kernel(const pq_page_desc *__re
         SegLook *L = looks + pg.seg_first;
         const uint32_t need = min(d.n_values, pg.total);
         const uint64_t V = 128ull << (pg.lg - 5u);
-        SegScan a = pg.lg == 5u ? seg_scan<5>(lds, S, len, s, pg.seg_bytes, pg.pos0, lane)
-                                : seg_scan<6>(lds, S, len, s, pg.seg_bytes, pg.pos0, lane);
+        SegScan a = pg.lg == 5u ? seg_scan<5>(lds, S, len, s, pg.seg_bytes, pg.pos0, lane, tab, tab_n)
+                                : seg_scan<6>(lds, S, len, s, pg.seg_bytes, pg.pos0, lane, tab, tab_n);
         uint64_t blocks = 0, carry = pg.first;
         uint32_t entry = pg.pos0;
+        int64_t md0 = 0;  // the first block's minDelta: the walk of segment 0 has read it, the others are told
         if (s != 0u) {
             if (lane == 0) look_show_summary(L + s, a);
             SegIn in = seg_look_back(L, s, lane, V, spin_limit);
@@ -633,13 +660,15 @@ __global__ __launch_bounds__(kWG) void seg_fused_kernel(const pq_page_desc *__re
                 return;
             }
             if (a.key != in.want_key)  // the guess was elsewhere: once more, from where the chain says
-                a = pg.lg == 5u ? seg_scan<5>(lds, S, len, s, pg.seg_bytes, pg.pos0, lane, in.want_key)
-                                : seg_scan<6>(lds, S, len, s, pg.seg_bytes, pg.pos0, lane, in.want_key);
+                a = pg.lg == 5u ? seg_scan<5>(lds, S, len, s, pg.seg_bytes, pg.pos0, lane, tab, tab_n, in.want_key)
+                                : seg_scan<6>(lds, S, len, s, pg.seg_bytes, pg.pos0, lane, tab, tab_n, in.want_key);
             blocks = in.blocks;
             carry = in.carry;
             entry = in.entry;
+            md0 = in.md;
             a.sum += a.nblk != 0u ? V * (uint64_t)in.md : 0ull;
         }
+        if (s == 0u && tab_n != 0u) md0 = (int64_t)(((uint64_t)uni(tab[3]) << 32) | uni(tab[2]));
         // the last one with a wave of its own: nothing to go on from, or nothing wanted behind it
         tail = a.exit_key == kSegNone || s + 1u == pg.n_segs || V * (blocks + a.nblk) >= (uint64_t)need;
         if (lane == 0) {
@@ -667,7 +696,7 @@ __global__ __launch_bounds__(kWG) void seg_fused_kernel(const pq_page_desc *__re
         wave_sync();
         if (pg.lg == 5u)
             r = delta_wave_tiles<UT, 5, false, true>(lds, S, len, d.n_values, dst, lane, pf, c0, (int64_t)entry, pg.total,
-                                                     carry, vec_ok, nullptr, (uint32_t)(V * blocks), stop);
+                                                     carry, vec_ok, nullptr, (uint32_t)(V * blocks), stop, tab, tab_n, md0);
         else
             r = delta_wave_tiles<UT, 6, false, true>(lds, S, len, d.n_values, dst, lane, pf, c0, (int64_t)entry, pg.total,
                                                      carry, vec_ok, nullptr, (uint32_t)(V * blocks), stop);
