@@ -36,6 +36,12 @@ func NewCtx(device int) (*Ctx, error) {
 	return ctx, nil
 }
 
+// SetOption sets one of the PQ_OPT_* knobs of pqdecode.h (segment length, page limits of the
+// segmented decodes, groups of a plan side by side, ...) for the plans this context creates next.
+func (x *Ctx) SetOption(option int, value int64) error {
+	return statusErr(C.pq_ctx_set_option(x.c, C.int(option), C.int64_t(value)))
+}
+
 // statusErr maps the integer status back to the errors the Go decoders return, so callers that
 // test errors.Cause(err) == io.EOF keep working.
 func statusErr(st C.int) error {

@@ -114,6 +114,7 @@ struct pq_plan {
         uint32_t *d_seg_owner = nullptr, *d_check_owner = nullptr, *d_counts = nullptr;
         pq::HsegRec *d_recs = nullptr;
         pq::HsegScan *d_scans = nullptr;  // two records per segment
+        uint16_t *d_tabs = nullptr;       // run-header offsets the scans leave for the decode (HsegPage::tab_first)
     } hs[2];
     // large pages of nested columns run as three units each (nested.hip): the internal table holds
     // n_total = n + 2 * n_split descriptors and results, the caller sees the first n
@@ -216,8 +217,9 @@ uint32_t value_size(const pq_page_desc &d)
 // (max_def != 0: the constant level 0 never equals it), empty pages and V2 pages whose level bytes
 // are not all there stay with the page kernels.
 constexpr uint64_t kSegValues = 8192;        // values a segment of a run-dense hybrid stream aims at
-constexpr uint32_t kNestedSplitMin = 65536;
-constexpr uint64_t kForkMinBytes = 16ull << 20;  // a lane of a plan with less to move than this is not worth a fork  // level slots from which a nested page is worth three units
+constexpr uint64_t kHsegTableMax = 2ull << 30;  // bytes of run-header offsets a plan keeps for its cut hybrid streams at most
+constexpr uint32_t kNestedSplitMin = 65536;  // level slots from which a nested page is worth three units
+constexpr uint64_t kForkMinBytes = 16ull << 20;  // a lane of a plan with less to move than this is not worth a fork
 constexpr uint32_t kFlagLowered = 0x80000000u;  // internal: never set by callers (validate refuses it)
 
 bool lower_flat_page(pq_page_desc &d)
@@ -742,6 +744,7 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
     struct HsegHost {
         std::vector<pq::HsegPage> pages;
         std::vector<uint32_t> seg_owner, check_owner;
+        uint64_t tab_entries = 0;  // 16-bit entries of the run-header table, a multiple of 8 per page
     } hsh[2];
     auto build_hseg = [&](std::vector<uint32_t> &g, HsegHost &out, bool units) {
         if (g.empty() || (!units && g.size() >= ctx->seg_max_pages)) return;
@@ -785,6 +788,10 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
             pg.seg_bytes = (uint32_t)Lp;
             pg.check_first = (uint32_t)out.check_owner.size();
             pg.n_checks = units ? 0u : (uint32_t)((sb + 4095) / 4096);  // level streams are never chains of equal runs
+            // the offsets of a segment's run headers, for the decode behind the scan: two bytes of table
+            // per two bytes of stream the segments can hold
+            pg.tab_first = (uint32_t)(out.tab_entries / 8u);
+            out.tab_entries += ((uint64_t)pg.n_segs * (pg.seg_bytes / 2u) + 7u) & ~7ull;
             out.seg_owner.insert(out.seg_owner.end(), pg.n_segs, (uint32_t)out.pages.size());
             out.check_owner.insert(out.check_owner.end(), pg.n_checks, (uint32_t)out.pages.size());
             out.pages.push_back(pg);
@@ -792,6 +799,11 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
     };
     build_hseg(ids[0], hsh[0], false);
     build_hseg(ids[6], hsh[1], true);
+    for (HsegHost &h : hsh)
+        if (h.tab_entries * sizeof(uint16_t) > kHsegTableMax) {  // too much to keep: the decode finds the headers itself
+            h.tab_entries = 0;
+            for (pq::HsegPage &pg : h.pages) pg.tab_first = 0xffffffffu;
+        }
     for (int k = 0; k < 2; ++k) {
         plan->hs[k].n_pages = (uint32_t)hsh[k].pages.size();
         plan->hs[k].n_segs = (uint32_t)hsh[k].seg_owner.size();
@@ -847,11 +859,12 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
         for (int k = 0; k < 2; ++k) r_sr[k] = take(seg_owner[k].size() * sizeof(pq::SegRec));
         Region r_sl[2];
         for (int k = 0; k < 2; ++k) r_sl[k] = take(seg_owner[k].size() * sizeof(pq::SegLook));
-        Region r_hr[2], r_hn[2], r_hx[2];
+        Region r_hr[2], r_hn[2], r_hx[2], r_ht[2];
         for (int k = 0; k < 2; ++k) {
             r_hr[k] = take(hsh[k].seg_owner.size() * sizeof(pq::HsegRec));
             r_hn[k] = take(hsh[k].check_owner.size() * sizeof(uint32_t));
             r_hx[k] = take(2 * hsh[k].seg_owner.size() * sizeof(pq::HsegScan));
+            r_ht[k] = take(hsh[k].tab_entries * sizeof(uint16_t));
         }
         const size_t total = img;
         uint8_t *block = nullptr;
@@ -906,6 +919,7 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
                 hd.d_recs = reinterpret_cast<pq::HsegRec *>(block + r_hr[k].at);
                 hd.d_counts = reinterpret_cast<uint32_t *>(block + r_hn[k].at);
                 hd.d_scans = reinterpret_cast<pq::HsegScan *>(block + r_hx[k].at);
+                hd.d_tabs = r_ht[k].bytes ? reinterpret_cast<uint16_t *>(block + r_ht[k].at) : nullptr;
                 put(r_hp[k], hsh[k].pages.data());
                 put(r_hs[k], hsh[k].seg_owner.data());
                 put(r_hc[k], hsh[k].check_owner.data());
@@ -995,7 +1009,7 @@ static int plan_launch(pq_plan *plan, pq::PageBuffers buf)
     auto seg_hybrid = [&](const pq_plan::HsegDev &hd) {
         return pq::launch_seg_hybrid(ctx->stream, plan->d_descs, hd.d_pages, hd.n_pages, hd.d_check_owner, hd.n_checks,
                                      hd.d_counts, hd.d_seg_owner, hd.n_segs, hd.d_recs, hd.d_scans, buf, plan->d_results,
-                                     plan->dict_lds_bytes);
+                                     plan->dict_lds_bytes, hd.d_tabs);
     };
     if (plan->n_split != 0) {
         // large nested pages: where their three sections lie, then the level units; the values run
@@ -1038,7 +1052,7 @@ static int plan_launch(pq_plan *plan, pq::PageBuffers buf)
         const pq_plan::HsegDev &hd = plan->hs[0];
         return pq::launch_seg_hybrid(st, plan->d_descs, hd.d_pages, hd.n_pages, hd.d_check_owner, hd.n_checks, hd.d_counts,
                                      hd.d_seg_owner, hd.n_segs, hd.d_recs, hd.d_scans, buf, plan->d_results,
-                                     plan->dict_lds_bytes);
+                                     plan->dict_lds_bytes, hd.d_tabs);
     };
     PQ_HIP(ctx, seg_hybrid0(lane[0]));
     PQ_HIP(ctx, pq::launch_stream_pages(lane[0], plan->d_descs, plan->d_ids + plan->first[0], plan->count[0], buf,

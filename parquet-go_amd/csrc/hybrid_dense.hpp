@@ -162,6 +162,129 @@ __device__ __forceinline__ uint32_t dn_span(HybridWaveLds &L, uint32_t o, uint32
     return (uint32_t)__builtin_popcountll(tmask);
 }
 
+// The run headers of a stream as a walk in front of the decode found them (seghybrid.hip: the scan
+// of a segment notes the offset of every header it passes, 16 bits each, from the segment's first
+// header on).  The decode still reads every header itself; what the table saves is finding them.
+struct DnTable {
+    const uint16_t *tab;  // 16-byte aligned; nullptr: none
+    uint32_t tn;          // entries; 0: none (or given up: the stream is not where the table says)
+    uint32_t ti;          // entry of the next header, if the walk and the table are in step
+    uint16_t *cache;      // kDnTabCache entries of the table in LDS: [cbase, cbase + kDnTabCache)
+    uint32_t cbase;       // a multiple of 8
+};
+constexpr uint32_t kDnNoTable = 0xfffffffeu;
+constexpr uint32_t kDnTabCache = 1024;  // entries: 16 per lane, two 16-byte loads
+
+__device__ __forceinline__ void dn_table_fill(DnTable &T, uint32_t base, int lane)
+{
+    wave_sync();  // earlier reads of the cache are done
+    const u32x4_t *src = reinterpret_cast<const u32x4_t *>(T.tab + base);
+    u32x4_t v[2];
+#pragma unroll
+    for (uint32_t k = 0; k < 2u; ++k) {
+        const uint32_t q = (uint32_t)lane + (uint32_t)kWave * k;
+        v[k] = u32x4_t{0u, 0u, 0u, 0u};
+        if (base + 8u * q < T.tn) v[k] = src[q];  // the table's room is whole 16-byte pieces
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 2u; ++k) reinterpret_cast<u32x4_t *>(T.cache)[(uint32_t)lane + (uint32_t)kWave * k] = v[k];
+    wave_sync();
+    T.cbase = base;
+}
+
+// entry ti + lane, 0xffffffff behind the table's end
+__device__ __forceinline__ uint32_t dn_table_load(DnTable &T, uint32_t ti, int lane)
+{
+    if (ti < T.cbase || ti + (uint32_t)kWave > T.cbase + kDnTabCache) dn_table_fill(T, ti & ~7u, lane);
+    const uint32_t idx = ti + (uint32_t)lane;
+    return idx < T.tn ? (uint32_t)T.cache[idx - T.cbase] : 0xffffffffu;
+}
+
+// dn_span with the headers' places taken from the table: lane l parses run T.ti + l, so a step
+// covers up to 64 runs whatever bytes they take, and no chain is followed.  c0 = stream offset of
+// window byte 0.  Returns kDnNoTable (nothing changed, T.tn = 0) when the header at o is not in the
+// table: the caller goes on finding headers itself.
+__device__ __forceinline__ uint32_t dn_span_table(HybridWaveLds &L, uint32_t o, uint32_t wl, const HwConst &hc,
+                                                  uint32_t room, uint32_t np, uint32_t fill, uint32_t phase, int lane,
+                                                  uint32_t &values, DnNext &nx, DnTable &T, int32_t c0)
+{
+    const uint32_t here = o + (uint32_t)c0;  // stream offset of the header at o
+    uint32_t rel = dn_table_load(T, T.ti, lane);
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)rel) != here) {
+        // something else took runs since the last step (the bulk path, a checked tile): the entries
+        // are in stream order, look for this header further on
+        uint64_t m = 0;
+        for (uint32_t tries = 0; tries < 8u; ++tries) {
+            m = __builtin_amdgcn_ballot_w64(rel >= here);  // lanes behind the table's end hold 0xffffffff
+            if (m != 0ull) break;
+            T.ti += (uint32_t)kWave;
+            rel = dn_table_load(T, T.ti, lane);
+        }
+        const uint32_t k = m != 0ull ? (uint32_t)__builtin_ctzll(m) : 0u;
+        if (m == 0ull || (uint32_t)__builtin_amdgcn_readlane((int)rel, (int)k) != here) {
+            T.tn = 0;
+            return kDnNoTable;
+        }
+        T.ti += k;
+        if (k != 0u) rel = dn_table_load(T, T.ti, lane);
+    }
+    const uint32_t pr = rel - (uint32_t)c0;  // window offset of this lane's header
+    const bool inwin = rel != 0xffffffffu && pr < wl;
+    const uint32_t p = inwin ? pr : o;
+    const uint32_t i = p >> 2, sh = (p & 3u) * 8u;
+    const uint32_t d0 = L.window[i], d1 = L.window[i + 1], d2 = L.window[i + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh);  // bytes p .. p+3
+    const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, sh);  // bytes p+4 .. p+7
+    const bool two = (lo & 0x80u) != 0u;
+    const uint32_t hdr = two ? 2u : 1u;
+    const uint32_t h = two ? (lo & 0x7fu) | ((lo >> 1) & 0x3f80u) : lo & 0xffu;
+    const uint32_t cnt = h >> 1;
+    const bool isbp = (h & 1u) != 0u;
+    const uint32_t val = __builtin_amdgcn_alignbit(hi, lo, 8u * hdr) & hc.vbmask;
+    const uint32_t body = isbp ? __umul24(cnt, hc.w) : hc.vb;
+    const uint32_t hend = p + hdr + (isbp ? 0u : hc.vb);  // end of the header and, for RLE, its value
+    const uint32_t rend = p + hdr + body;                 // end of the run
+    const uint32_t nvals = isbp ? cnt * 8u : cnt;
+    const bool ok = inwin && (lo & 0x8080u) != 0x8080u && cnt != 0u && hend <= wl && (isbp || (val & ~hc.wmask) == 0u);
+    const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
+    const uint64_t wholemask = __builtin_amdgcn_ballot_w64(ok && rend <= wl);
+    values = 0;
+    nx.kind = 0;
+    nx.count = 0;
+    nx.value = 0;
+    nx.o = o;
+    if ((okmask & 1ull) == 0ull) return kDnOdd;  // T stays: a checked tile takes this run, the next step finds its place again
+    // the leading runs that lie wholly in the window
+    const uint32_t lead = ~wholemask != 0ull ? (uint32_t)__builtin_ctzll(~wholemask) : (uint32_t)kWave;
+    const uint64_t leadmask = lead >= 64u ? ~0ull : (1ull << lead) - 1ull;
+    const uint32_t incl = wave_scan_u32(dn_select(leadmask, nvals));
+    const bool fit = (uint32_t)lane < lead && incl <= room && np + (uint32_t)lane < (uint32_t)kWave;
+    const uint64_t tmask = __builtin_amdgcn_ballot_w64(fit);  // lanes 0 .. taken - 1
+    const uint32_t taken = (uint32_t)__builtin_popcountll(tmask);
+    if (taken != 0u) {
+        values = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(taken - 1u));
+        nx.o = (uint32_t)__builtin_amdgcn_readlane((int)rend, (int)(taken - 1u));
+    }
+    uint32_t adv = taken;
+    if (taken < (uint32_t)kWave && ((okmask >> taken) & 1ull) != 0ull) {
+        // a well-formed run that does not fit (the tile, the window, the piece table): the caller cuts it
+        const uint32_t hu = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)taken);
+        nx.kind = (hu & 1u) != 0u ? 2u : 1u;
+        nx.count = hu >> 1;
+        nx.value = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)taken);
+        nx.o = (uint32_t)__builtin_amdgcn_readlane((int)hend, (int)taken);
+        adv += 1u;
+    }
+    if (fit) {
+        const uint32_t start = fill + incl - nvals;
+        const uint32_t at = (p + hdr) * 8u;
+        L.pieces[np + (uint32_t)lane] = make_uint2(isbp ? at - __umul24(start, hc.w) : at, isbp ? hc.w : 0u);
+        reinterpret_cast<uint8_t *>(L.marks)[phase + start] = 1;
+    }
+    T.ti += adv;
+    return taken;
+}
+
 // 32 bits of the window from bit address `bit` on
 __device__ __forceinline__ uint32_t dn_read(const uint32_t *lds, uint32_t bit)
 {
@@ -295,7 +418,8 @@ template <int MODE, typename OutT, int Q>
 __device__ __forceinline__ uint32_t hw_dense_tiles(HybridWaveLds &L, HwState &st, const HwSink<OutT> &sink,
                                                    const HwConst &hc, uint32_t n, uint32_t mis, uint32_t wl,
                                                    uint32_t o_end, bool tail, uint32_t rw, bool allow_bulk, int lane,
-                                                   uint32_t &local_count, uint32_t &scount, bool &bad_index)
+                                                   uint32_t &local_count, uint32_t &scount, bool &bad_index,
+                                                   DnTable &T, int32_t c0)
 {
     constexpr uint32_t TILE = 256u * Q;
     const uint32_t w = hc.w;
@@ -372,7 +496,10 @@ __device__ __forceinline__ uint32_t hw_dense_tiles(HybridWaveLds &L, HwState &st
                 if (st.o >= wl) { reason = DN_GENERIC; break; }
                 uint32_t values;
                 DnNext nx;
-                const uint32_t taken = dn_span(L, st.o, wl, hc, want - fill, np, fill, phase, lane, values, nx, dense);
+                uint32_t taken = kDnNoTable;
+                if (T.tn != 0u) taken = dn_span_table(L, st.o, wl, hc, want - fill, np, fill, phase, lane, values, nx, T, c0);
+                if (taken == kDnNoTable)
+                    taken = dn_span(L, st.o, wl, hc, want - fill, np, fill, phase, lane, values, nx, dense);
                 if (taken == kDnOdd) { reason = DN_GENERIC; break; }
                 np += taken;
                 fill += values;

@@ -464,7 +464,9 @@ namespace pq {
 template <int MODE, typename OutT>
 __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint8_t *S, int64_t len, uint32_t w,
                                                     uint32_t n, OutT *dst, const OutT *dict, uint32_t dict_len,
-                                                    uint32_t max_level, int lane, uint32_t raw_groups = 0)
+                                                    uint32_t max_level, int lane, uint32_t raw_groups = 0,
+                                                    const uint16_t *tab = nullptr, uint32_t tab_n = 0,
+                                                    uint16_t *tab_cache = nullptr)
 {
     HybridResult res{PQ_OK, 0, 0, 0};
     const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(dst) / sizeof(OutT)) & 3u);
@@ -524,6 +526,13 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
     uint32_t scount = 0;       // LEVELS: the same, counted for whole tiles of one RLE run
     uint32_t stuck_v = 0xffffffffu;  // st.v when the run-dense tiles last handed a run to the bulk path
     bool bad_index = false;    // DICT: a key outside the dictionary seen by this lane
+    DnTable T;                 // where a walk in front of this decode found the run headers, if one was made
+    T.tab = tab;
+    T.tn = tab != nullptr && tab_cache != nullptr ? tab_n : 0u;
+    T.ti = 0;
+    T.cache = tab_cache;
+    T.cbase = 0;
+    if (T.tn != 0u) dn_table_fill(T, 0, lane);
 
     while (true) {
         const int64_t c1 = c0 + kHwStride;
@@ -609,7 +618,8 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
         if (vec_ok) {
             const bool allow_bulk = st.v != stuck_v;
             const uint32_t why = hw_dense_tiles<MODE, OutT, MODE == HY_DICT ? kDnQuads : kDnQuadsPlain>(
-                L, st, sink, hc, n, mis, wl, o_end, tail, rw, allow_bulk, lane, local_count, scount, bad_index);
+                L, st, sink, hc, n, mis, wl, o_end, tail, rw, allow_bulk, lane, local_count, scount, bad_index, T,
+                (int32_t)c0);
             if (why == DN_DONE) { done = true; break; }
             if (why == DN_WINDOW) break;
             if (why == DN_BULK) { stuck_v = st.v; continue; }

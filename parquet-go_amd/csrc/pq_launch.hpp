@@ -147,7 +147,8 @@ struct HsegPage {
     uint32_t kind_mode;    // HY_RAW, HY_DICT or HY_LEVELS: what the decode does with a value
     uint32_t max_level;    // HY_LEVELS
     uint32_t fixed_consumed;  // != 0xffffffff: the consumed bytes the result reports (InitSize, buffered Init)
-    uint32_t pad;
+    uint32_t tab_first;    // mode 2: where the page's run-header offsets start in the plan's table, in units of
+                           // 8 entries (0xffffffff: the plan keeps none); n_segs * seg_bytes / 2 entries
 };
 struct HsegRec {
     uint64_t off;        // stream offset the segment starts at
@@ -159,7 +160,7 @@ struct HsegRec {
     uint32_t count_max;  // HY_LEVELS: values equal to the maximum level
     uint64_t consumed;
     uint32_t len;        // bytes of the stream it may read
-    uint32_t pad;
+    uint32_t runs;       // mode 2: run-header offsets the walk left in the segment's part of the table
 };
 // Mode 2: what a walk over the headers of one segment found.
 struct HsegScan {
@@ -167,13 +168,15 @@ struct HsegScan {
     uint32_t exit;   // offset of the first run header at or behind its end (0xffffffff: the walk ran into
                      // something that is not a complete, well-formed run)
     uint32_t nvals;  // values of the runs from entry to exit (saturating at 2^31 - 1)
-    uint32_t pad;
+    uint32_t runs;   // header offsets (from entry on, 16 bits each) the walk wrote to the segment's part of the
+                     // table: all of its runs, or 0
 };
 // d_check_owner / d_seg_owner: counter -> page and segment -> page maps.  d_scans: 2 * n_segs records.
+// d_tabs: the run-header table HsegPage::tab_first points into, or nullptr.
 hipError_t launch_seg_hybrid(hipStream_t s, const pq_page_desc *d_descs, HsegPage *d_pages, uint32_t n_pages,
                              const uint32_t *d_check_owner, uint32_t n_checks, uint32_t *d_counts,
                              const uint32_t *d_seg_owner, uint32_t n_segs, HsegRec *d_recs, HsegScan *d_scans,
-                             PageBuffers buf, pq_page_result *d_results, uint32_t dict_lds_bytes);
+                             PageBuffers buf, pq_page_result *d_results, uint32_t dict_lds_bytes, uint16_t *d_tabs);
 
 // ---- large nested pages as three units (nested.hip) ---------------------------------------------
 // The host fills the first nine fields; the rest is written on the device every run.

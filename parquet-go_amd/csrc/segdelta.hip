@@ -643,13 +643,19 @@ __global__ __launch_bounds__(kWG) void seg_fused_kernel(const pq_page_desc *__re
             if (in.status != kInOk) {
                 if (lane == 0) {
                     if (in.status == kInGaveUp) {
-                        // The page goes to the sweep kernel behind this one, whole.  Every segment behind
-                        // this one gives up too, so no wave reaches the page's end and writes over the mark;
-                        // when it is a segment behind the page's last value that gave up, the page is
-                        // complete either way and whichever write comes last is right.
+                        // The page goes to the sweep kernel behind this one, whole.  A segment behind this
+                        // one may still find its place (it looks past this one's summary at segments that
+                        // have shown theirs in the meantime), so the wave that reaches the page's end may
+                        // write the page's result while this one writes its mark.  The mark has to be what
+                        // stays: the page's word first, and only when it has arrived the status; the wave
+                        // at the page's end writes its result first and looks at the page's word when that
+                        // has arrived.  Either it sees the word, or its result was there before the word
+                        // and so before the status written here.
                         look_show_gave_up(L + s);
                         __hip_atomic_store(&pages[pi].giveup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        results[pg.desc].status = kNeedGeneric;
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __hip_atomic_store(&results[pg.desc].status, (int32_t)kNeedGeneric, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
                         *flag = epoch;
                     } else {
                         look_show_place(L + s, 0ull, 0ull, kSegNone, kSegNone, 0u);
@@ -714,6 +720,15 @@ __global__ __launch_bounds__(kWG) void seg_fused_kernel(const pq_page_desc *__re
         res.consumed = r.consumed;
         results[pg.desc] = res;
         if (r.status == kNeedGeneric) *flag = epoch;  // wakes the sweep kernel
+        if (!pg.whole) {
+            // a wave of this page that gave up (see above): its mark stays
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (__hip_atomic_load(&pages[pi].giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(&results[pg.desc].status, (int32_t)kNeedGeneric, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                *flag = epoch;
+            }
+        }
     }
 }
 

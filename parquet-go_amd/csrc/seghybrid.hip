@@ -164,7 +164,8 @@ __global__ __launch_bounds__(kWG) void hseg_check_kernel(const pq_page_desc *__r
     if (lane == 0) counts[g] = lead;
 }
 
-__device__ __forceinline__ HsegRec hseg_rec(uint64_t off, uint32_t len, uint32_t v0, uint32_t count, uint32_t flags)
+__device__ __forceinline__ HsegRec hseg_rec(uint64_t off, uint32_t len, uint32_t v0, uint32_t count, uint32_t flags,
+                                            uint32_t runs = 0)
 {
     HsegRec r;
     r.off = off;
@@ -176,7 +177,7 @@ __device__ __forceinline__ HsegRec hseg_rec(uint64_t off, uint32_t len, uint32_t
     r.count_max = 0;
     r.consumed = 0;
     r.len = len;
-    r.pad = 0;
+    r.runs = runs;
     return r;
 }
 
@@ -260,8 +261,12 @@ struct LsEnd {
     uint32_t dead;
 };
 
+// tab != nullptr (COUNT only): entry tn, tn + 1, ... of it receive the offsets, from `from` on, of the
+// headers passed (the one at or behind the boundary is not among them); tn may come out above tcap,
+// nothing is written beyond it.
 template <bool COUNT>
-__device__ __forceinline__ LsEnd ls_walk(LsWalk &W, uint32_t from, uint32_t boundary, uint64_t &acc, int lane)
+__device__ __forceinline__ LsEnd ls_walk(LsWalk &W, uint32_t from, uint32_t boundary, uint64_t &acc, int lane,
+                                         uint16_t *tab = nullptr, uint32_t *tn = nullptr, uint32_t tcap = 0)
 {
     // stream offsets are below 2^31 (hseg_header_kernel), so 32-bit unsigned arithmetic holds them
     uint32_t o = from;
@@ -316,6 +321,12 @@ __device__ __forceinline__ LsEnd ls_walk(LsWalk &W, uint32_t from, uint32_t boun
         const uint64_t below = brel < 64u ? ~(~0ull << brel) : ~0ull;
         const uint64_t over = chain & ~below;
         if (COUNT) acc += dn_select(chain & below, nvals);
+        if (COUNT && tab != nullptr) {
+            const uint64_t in = chain & below;
+            const uint32_t slot = *tn + __builtin_amdgcn_mbcnt_hi((uint32_t)(in >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)in, 0u));
+            if (((in >> lane) & 1ull) != 0ull && slot < tcap) tab[slot] = (uint16_t)(o + (uint32_t)lane - from);
+            *tn += (uint32_t)__builtin_popcountll(in);
+        }
         if (over != 0ull) return LsEnd{o + (uint32_t)__builtin_ctzll(over), 0u};
         if (cur >= 64u) {  // the last run of the span ends behind it (inside the stream: cur <= end - o)
             o += cur;
@@ -346,6 +357,10 @@ __device__ __forceinline__ LsEnd ls_walk(LsWalk &W, uint32_t from, uint32_t boun
         }
         if (next > (uint64_t)end) return LsEnd{kLsNone, at};
         if (COUNT && lane == 0) acc += nv;
+        if (COUNT && tab != nullptr) {
+            if (lane == 0 && *tn < tcap) tab[*tn] = (uint16_t)(at - from);
+            *tn += 1u;
+        }
         o = (uint32_t)next;
     }
     return LsEnd{o, 0u};
@@ -366,16 +381,21 @@ __device__ __forceinline__ void ls_init(LsWalk &W, uint32_t *lds, const uint8_t 
 }
 
 // The segment from `entry` on: where the chain leaves it and how many values it passes.
-__device__ __forceinline__ HsegScan ls_segment(LsWalk &W, uint32_t entry, uint32_t hi, int lane)
+// tab: room for tcap header offsets of this segment's runs (nullptr: none kept); sc.runs says how
+// many were written.
+__device__ __forceinline__ HsegScan ls_segment(LsWalk &W, uint32_t entry, uint32_t hi, int lane, uint16_t *tab,
+                                               uint32_t tcap)
 {
     HsegScan sc;
     sc.entry = entry;
     sc.exit = entry;
     sc.nvals = 0;
-    sc.pad = 0;
+    sc.runs = 0;
     if (entry == kLsNone || entry >= hi) return sc;  // a long run covers the whole segment: nothing starts here
     uint64_t acc = 0;
-    sc.exit = ls_walk<true>(W, entry, hi, acc, lane).at;
+    uint32_t tn = 0;
+    sc.exit = ls_walk<true>(W, entry, hi, acc, lane, tab, &tn, tcap).at;
+    sc.runs = tab != nullptr && tn <= tcap ? tn : 0u;
     const uint64_t total = wave_last_u64(wave_scan_u64(acc));
     sc.nvals = total > 0x7fffffffull ? 0x7fffffffu : (uint32_t)total;
     return sc;
@@ -383,10 +403,21 @@ __device__ __forceinline__ HsegScan ls_segment(LsWalk &W, uint32_t entry, uint32
 
 constexpr uint32_t kLsLdsWords = kHwChunk / 4 + kHwSlack;
 
+// Segment s of a page keeps the offsets of its run headers in entries [s * seg_bytes / 2, ...) of the
+// page's part of the table: a run is two bytes and more (the width is at least 1), so the k-th header
+// of a segment lies 2 k bytes and more behind the segment's first byte, and the entries of one
+// segment end in front of the next one's.
+__device__ __forceinline__ uint16_t *ls_table(uint16_t *tabs, const HsegPage &pg, uint32_t s)
+{
+    if (tabs == nullptr || pg.tab_first == kLsNone || (pg.seg_bytes & 15u) != 0u || pg.seg_bytes > 65536u) return nullptr;
+    return tabs + (size_t)pg.tab_first * 8u + (size_t)s * (pg.seg_bytes / 2u);
+}
+
 __global__ __launch_bounds__(kWG) void lseg_scan_kernel(const pq_page_desc *__restrict__ descs,
                                                         const HsegPage *__restrict__ pages,
                                                         const uint32_t *__restrict__ owner, uint32_t n_segs,
-                                                        HsegScan *__restrict__ scans, PageBuffers buf)
+                                                        HsegScan *__restrict__ scans, PageBuffers buf,
+                                                        uint16_t *__restrict__ tabs)
 {
     __shared__ __attribute__((aligned(16))) uint32_t window[kWG / kWave][kLsLdsWords];
     const int lane = threadIdx.x & (kWave - 1);
@@ -401,7 +432,7 @@ __global__ __launch_bounds__(kWG) void lseg_scan_kernel(const pq_page_desc *__re
     sc.entry = kLsNone;
     sc.exit = kLsNone;
     sc.nvals = 0;
-    sc.pad = 0;
+    sc.runs = 0;
     if (lo64 < (uint64_t)pg.end) {
         const pq_page_desc d = descs[pg.desc];
         LsWalk W;
@@ -426,7 +457,7 @@ __global__ __launch_bounds__(kWG) void lseg_scan_kernel(const pq_page_desc *__re
                 if (o >= lo) break;
             }
         }
-        sc = ls_segment(W, entry, hi, lane);
+        sc = ls_segment(W, entry, hi, lane, ls_table(tabs, pg, s), pg.seg_bytes / 2u);
     }
     if (lane == 0) scans[g] = sc;
 }
@@ -437,7 +468,7 @@ __global__ __launch_bounds__(kWG) void lseg_fix_kernel(const pq_page_desc *__res
                                                        const HsegPage *__restrict__ pages,
                                                        const uint32_t *__restrict__ owner, uint32_t n_segs,
                                                        const HsegScan *__restrict__ in, HsegScan *__restrict__ out,
-                                                       PageBuffers buf)
+                                                       PageBuffers buf, uint16_t *__restrict__ tabs)
 {
     __shared__ __attribute__((aligned(16))) uint32_t window[kWG / kWave][kLsLdsWords];
     const int lane = threadIdx.x & (kWave - 1);
@@ -456,7 +487,7 @@ __global__ __launch_bounds__(kWG) void lseg_fix_kernel(const pq_page_desc *__res
             LsWalk W;
             ls_init(W, window[wave], buf.src + d.src_off, pg, lane);
             const uint32_t hi = (uint32_t)min(lo64 + pg.seg_bytes, (uint64_t)pg.end);
-            sc = ls_segment(W, px, hi, lane);
+            sc = ls_segment(W, px, hi, lane, ls_table(tabs, pg, s), pg.seg_bytes / 2u);
         }
     }
     if (lane == 0) out[g] = sc;
@@ -465,7 +496,7 @@ __global__ __launch_bounds__(kWG) void lseg_fix_kernel(const pq_page_desc *__res
 __global__ __launch_bounds__(kWG) void lseg_link_kernel(const pq_page_desc *__restrict__ descs,
                                                         HsegPage *__restrict__ pages, uint32_t n_pages,
                                                         HsegScan *__restrict__ scans, HsegRec *__restrict__ recs,
-                                                        PageBuffers buf)
+                                                        PageBuffers buf, uint16_t *__restrict__ tabs)
 {
     __shared__ __attribute__((aligned(16))) uint32_t window[kWG / kWave][kLsLdsWords];
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -492,11 +523,12 @@ __global__ __launch_bounds__(kWG) void lseg_link_kernel(const pq_page_desc *__re
         sc.entry = kLsNone;
         sc.exit = kLsNone;
         sc.nvals = 0;
-        sc.pad = 0;
+        sc.runs = 0;
         if (valid) {  // records another lane of this wave may have rewritten a moment ago: not through the L1
             sc.entry = __atomic_load_n(&SC[s].entry, __ATOMIC_RELAXED);
             sc.exit = __atomic_load_n(&SC[s].exit, __ATOMIC_RELAXED);
             sc.nvals = __atomic_load_n(&SC[s].nvals, __ATOMIC_RELAXED);
+            sc.runs = __atomic_load_n(&SC[s].runs, __ATOMIC_RELAXED);
         }
         uint32_t px = (uint32_t)__shfl_up((int)sc.exit, 1);
         if (lane == 0) px = prev_exit;
@@ -519,14 +551,14 @@ __global__ __launch_bounds__(kWG) void lseg_link_kernel(const pq_page_desc *__re
                 const uint32_t hi = (uint32_t)min(lo64 + pg.seg_bytes, (uint64_t)pg.end);
                 // stepping over a long run costs nothing and does not count
                 if (want_entry < hi) repairs += 1u;
-                const HsegScan fixed = ls_segment(W, want_entry, hi, (int)lane);
+                const HsegScan fixed = ls_segment(W, want_entry, hi, (int)lane, ls_table(tabs, pg, sk), pg.seg_bytes / 2u);
                 if (lane == 0) SC[sk] = fixed;
                 __threadfence();  // lane 0 wrote the record; every lane reads it next
                 continue;         // the same 64 segments once more
             }
         }
         if (valid && lane < first_bad)
-            R[s] = hseg_rec(sc.entry, sc.exit != kLsNone ? sc.exit - sc.entry : 0u, (uint32_t)v0, sc.nvals, kSegPart);
+            R[s] = hseg_rec(sc.entry, sc.exit != kLsNone ? sc.exit - sc.entry : 0u, (uint32_t)v0, sc.nvals, kSegPart, sc.runs);
         if (bad != 0ull) {
             K = base + first_bad;
             break;
@@ -547,7 +579,7 @@ __global__ __launch_bounds__(kWG) void lseg_link_kernel(const pq_page_desc *__re
         if (s + 1u < K) continue;
         if (s + 1u == K) {
             const HsegRec r = R[s];
-            R[s] = hseg_rec(r.off, pg.end - (uint32_t)r.off, r.v0, (uint32_t)(n - (uint64_t)r.v0), kSegTail);
+            R[s] = hseg_rec(r.off, pg.end - (uint32_t)r.off, r.v0, (uint32_t)(n - (uint64_t)r.v0), kSegTail, r.runs);
         } else {
             R[s] = hseg_rec(0, 0, 0, 0, kSegSkip);
         }
@@ -557,31 +589,38 @@ __global__ __launch_bounds__(kWG) void lseg_link_kernel(const pq_page_desc *__re
 
 // ---- decode ---------------------------------------------------------------------------------------
 
+// LDS of the decode kernel: a HybridWaveLds and a piece of the run-header table per wave, the dictionary behind
+constexpr uint32_t kHsLdsFixed =
+    hs_align16((uint32_t)sizeof(HybridWaveLds) * kHsWaves) + kHsWaves * kDnTabCache * (uint32_t)sizeof(uint16_t);
+
 template <typename OutT>
 __device__ __forceinline__ HybridResult hseg_values(HybridWaveLds &L, uint32_t kind_mode, const uint8_t *S, int64_t len,
                                                     uint32_t w, uint32_t n, uint8_t *dst, const uint8_t *gdict,
                                                     const uint32_t *ldict, uint32_t dict_len, uint32_t max_level,
-                                                    int lane)
+                                                    int lane, const uint16_t *tab, uint32_t runs, uint16_t *tcache)
 {
     if (kind_mode == HY_DICT) {
         const OutT *dict = ldict ? reinterpret_cast<const OutT *>(ldict) : reinterpret_cast<const OutT *>(gdict);
-        return hybrid_wave<HY_DICT, OutT>(L, S, len, w, n, reinterpret_cast<OutT *>(dst), dict, dict_len, 0, lane);
+        return hybrid_wave<HY_DICT, OutT>(L, S, len, w, n, reinterpret_cast<OutT *>(dst), dict, dict_len, 0, lane, 0, tab,
+                                          runs, tcache);
     }
     if (kind_mode == HY_LEVELS)
         return hybrid_wave<HY_LEVELS, uint32_t>(L, S, len, w, n, reinterpret_cast<uint32_t *>(dst), nullptr, 0, max_level,
-                                                lane);
-    return hybrid_wave<HY_RAW, uint32_t>(L, S, len, w, n, reinterpret_cast<uint32_t *>(dst), nullptr, 0, 0, lane);
+                                                lane, 0, tab, runs, tcache);
+    return hybrid_wave<HY_RAW, uint32_t>(L, S, len, w, n, reinterpret_cast<uint32_t *>(dst), nullptr, 0, 0, lane, 0, tab,
+                                         runs, tcache);
 }
 
 __global__ __launch_bounds__(kHsWG) void hseg_decode_kernel(const pq_page_desc *__restrict__ descs,
                                                             const HsegPage *__restrict__ pages,
                                                             const uint32_t *__restrict__ seg_owner, uint32_t n_segs,
                                                             HsegRec *__restrict__ recs, PageBuffers buf,
-                                                            uint32_t dict_lds_bytes)
+                                                            uint32_t dict_lds_bytes, uint16_t *__restrict__ tabs)
 {
     HybridWaveLds *LW = reinterpret_cast<HybridWaveLds *>(pq_hs_smem);
     // the workgroup's LDS copy of a dictionary: the one its first segment's page reads, if it fits
-    uint32_t *ld = reinterpret_cast<uint32_t *>(pq_hs_smem + hs_align16((uint32_t)sizeof(HybridWaveLds) * kHsWaves));
+    uint16_t *tcaches = reinterpret_cast<uint16_t *>(pq_hs_smem + hs_align16((uint32_t)sizeof(HybridWaveLds) * kHsWaves));
+    uint32_t *ld = reinterpret_cast<uint32_t *>(pq_hs_smem + kHsLdsFixed);
     uint64_t have_off = 0;
     uint32_t have_bytes = 0;
     {
@@ -619,12 +658,15 @@ __global__ __launch_bounds__(kHsWG) void hseg_decode_kernel(const pq_page_desc *
     // a proven segment is exactly its runs; the tail is everything from its first byte on
     const int64_t slen = (int64_t)uni(rec.len);
     uint8_t *sdst = dst + (size_t)v0 * es;
+    // mode 2: where the segment's run headers are, as the walk that proved it found them
+    const uint32_t runs = uni(rec.runs);
+    const uint16_t *tab = pg.mode == 2u && runs != 0u ? ls_table(tabs, pg, g - pg.seg_first) : nullptr;
     HybridResult r{PQ_OK, 0, 0, 0};
     if (count != 0u || flags == kSegTail)
         r = es == 8u ? hseg_values<uint64_t>(L, pg.kind_mode, S + off, slen, pg.w, count, sdst, gdict, ldict, d.dict_len,
-                                             pg.max_level, lane)
+                                             pg.max_level, lane, tab, runs, tcaches + kDnTabCache * (uint32_t)wave)
                      : hseg_values<uint32_t>(L, pg.kind_mode, S + off, slen, pg.w, count, sdst, gdict, ldict, d.dict_len,
-                                             pg.max_level, lane);
+                                             pg.max_level, lane, tab, runs, tcaches + kDnTabCache * (uint32_t)wave);
     if (lane == 0) {
         recs[g].status = r.status;
         recs[g].n_decoded = r.n_decoded;
@@ -680,7 +722,7 @@ __global__ __launch_bounds__(kWG) void hseg_final_kernel(const HsegPage *__restr
 hipError_t launch_seg_hybrid(hipStream_t s, const pq_page_desc *d_descs, HsegPage *d_pages, uint32_t n_pages,
                              const uint32_t *d_check_owner, uint32_t n_checks, uint32_t *d_counts,
                              const uint32_t *d_seg_owner, uint32_t n_segs, HsegRec *d_recs, HsegScan *d_scans,
-                             PageBuffers buf, pq_page_result *d_results, uint32_t dict_lds_bytes)
+                             PageBuffers buf, pq_page_result *d_results, uint32_t dict_lds_bytes, uint16_t *d_tabs)
 {
     if (n_pages == 0 || n_segs == 0) return hipSuccess;
     const uint32_t per = kWG / kWave;
@@ -692,23 +734,23 @@ hipError_t launch_seg_hybrid(hipStream_t s, const pq_page_desc *d_descs, HsegPag
                            d_check_owner, n_checks, d_counts, buf);
     hipLaunchKernelGGL(hseg_link_kernel, gp, dim3(kWG), 0, s, d_descs, d_pages, n_pages, d_counts, d_recs);
     // d_scans: two arrays of n_segs records, the second the first after the fix pass
-    hipLaunchKernelGGL(lseg_scan_kernel, gs, dim3(kWG), 0, s, d_descs, d_pages, d_seg_owner, n_segs, d_scans, buf);
+    hipLaunchKernelGGL(lseg_scan_kernel, gs, dim3(kWG), 0, s, d_descs, d_pages, d_seg_owner, n_segs, d_scans, buf, d_tabs);
     // two rounds: a segment entered at the wrong place usually still leaves at the right one (its walk
     // falls into step inside it), so the first round sets most entries right and the second the few
     // whose predecessor's exit was itself wrong at first
     hipLaunchKernelGGL(lseg_fix_kernel, gs, dim3(kWG), 0, s, d_descs, d_pages, d_seg_owner, n_segs, d_scans, d_scans + n_segs,
-                       buf);
+                       buf, d_tabs);
     hipLaunchKernelGGL(lseg_fix_kernel, gs, dim3(kWG), 0, s, d_descs, d_pages, d_seg_owner, n_segs, d_scans + n_segs, d_scans,
-                       buf);
-    hipLaunchKernelGGL(lseg_link_kernel, gp, dim3(kWG), 0, s, d_descs, d_pages, n_pages, d_scans, d_recs, buf);
-    const size_t lds = hs_align16((uint32_t)sizeof(HybridWaveLds) * kHsWaves) + dict_lds_bytes;
+                       buf, d_tabs);
+    hipLaunchKernelGGL(lseg_link_kernel, gp, dim3(kWG), 0, s, d_descs, d_pages, n_pages, d_scans, d_recs, buf, d_tabs);
+    const size_t lds = kHsLdsFixed + dict_lds_bytes;
     if (lds > 65536) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(hseg_decode_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(hseg_decode_kernel, dim3((n_segs + kHsWaves - 1) / kHsWaves), dim3(kHsWG), lds, s, d_descs, d_pages,
-                       d_seg_owner, n_segs, d_recs, buf, dict_lds_bytes);
+                       d_seg_owner, n_segs, d_recs, buf, dict_lds_bytes, d_tabs);
     hipLaunchKernelGGL(hseg_final_kernel, gp, dim3(kWG), 0, s, d_pages, n_pages, d_recs, d_results);
     return hipGetLastError();
 }
