@@ -1009,7 +1009,8 @@ static int plan_launch(pq_plan *plan, pq::PageBuffers buf)
     auto seg_hybrid = [&](const pq_plan::HsegDev &hd) {
         return pq::launch_seg_hybrid(ctx->stream, plan->d_descs, hd.d_pages, hd.n_pages, hd.d_check_owner, hd.n_checks,
                                      hd.d_counts, hd.d_seg_owner, hd.n_segs, hd.d_recs, hd.d_scans, buf, plan->d_results,
-                                     plan->dict_lds_bytes, hd.d_tabs);
+                                     &hd == &plan->hs[1] ? 0u : plan->dict_lds_bytes,  // level units read no dictionary
+                                     hd.d_tabs);
     };
     if (plan->n_split != 0) {
         // large nested pages: where their three sections lie, then the level units; the values run
@@ -1052,7 +1053,8 @@ static int plan_launch(pq_plan *plan, pq::PageBuffers buf)
         const pq_plan::HsegDev &hd = plan->hs[0];
         return pq::launch_seg_hybrid(st, plan->d_descs, hd.d_pages, hd.n_pages, hd.d_check_owner, hd.n_checks, hd.d_counts,
                                      hd.d_seg_owner, hd.n_segs, hd.d_recs, hd.d_scans, buf, plan->d_results,
-                                     plan->dict_lds_bytes, hd.d_tabs);
+                                     &hd == &plan->hs[1] ? 0u : plan->dict_lds_bytes,  // level units read no dictionary
+                                     hd.d_tabs);
     };
     PQ_HIP(ctx, seg_hybrid0(lane[0]));
     PQ_HIP(ctx, pq::launch_stream_pages(lane[0], plan->d_descs, plan->d_ids + plan->first[0], plan->count[0], buf,

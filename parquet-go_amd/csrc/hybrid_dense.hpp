@@ -410,11 +410,158 @@ __device__ __forceinline__ void dn_expand_const(const HwSink<OutT> &sink, uint32
     }
 }
 
+// Whole tiles straight from the table of run headers, for as long as the table, the window and the
+// tile agree: lane l parses run ti + l, a prefix sum of the runs' lengths says which of them reach
+// into the tile [v, v + 256 Q), each of those writes its own piece (a run the tile's first value lies
+// inside is a piece whose position 0 is in front of the tile; a run that goes on behind the tile is
+// simply met again by the next one), and the tile is expanded.  No run is ever "pending" here: where
+// a tile ends inside a run, the next tile starts from the same table entry.  Whatever does not fit —
+// a header of three bytes and more, more than 64 runs in a tile, a tile the window does not hold
+// whole, the stream's last values — ends the loop with st describing exactly what is out, in the
+// terms of the loops below (which take the tile and come back).
+// posv: the positions of phase 0 (256 q + 4 lane + k).
+template <int MODE, typename OutT, int Q>
+__device__ __forceinline__ void hw_table_tiles(HybridWaveLds &L, HwState &st, const HwSink<OutT> &sink,
+                                               const HwConst &hc, uint32_t n, uint32_t wl, int lane,
+                                               uint32_t &local_count, bool &bad_index, DnTable &T, int32_t c0,
+                                               const uint32_t (&posv)[Q][4])
+{
+    constexpr uint32_t TILE = 256u * Q;
+    // ---- the run the walk stands at or in: the last header in front of `probe` ----
+    const uint32_t here = st.o + (uint32_t)c0;  // pend == 0: the next header; else a byte behind the pending run's header
+    const uint32_t probe = st.pend == 0u ? here + 1u : here;
+    uint32_t base = T.ti != 0u ? T.ti - 1u : 0u;
+    uint32_t found = 0xffffffffu;
+    for (uint32_t tries = 0; tries < 8u; ++tries) {
+        const uint32_t rel = dn_table_load(T, base, lane);
+        const uint32_t c = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(rel < probe));  // entries are in order
+        if (c == 0u) break;  // in front of where the search began: not this table's business
+        if (c < (uint32_t)kWave) {
+            found = base + c - 1u;
+            break;
+        }
+        base += (uint32_t)kWave - 1u;  // all 64 lie in front: the last of them may be the one
+    }
+    if (found == 0xffffffffu) {
+        T.tn = 0;
+        return;
+    }
+    uint32_t ti = found;        // the table entry of the run that holds value v (or starts with it)
+    uint32_t v = st.v;
+    uint32_t a = st.v;          // index of that run's first value
+    uint32_t o_cur = 0;         // window offset of its header
+    bool first = true;
+    for (;;) {
+        const uint32_t rel = dn_table_load(T, ti, lane);
+        const uint32_t pr = rel - (uint32_t)c0;
+        const bool inwin = rel != 0xffffffffu && pr < wl;
+        const uint32_t p = inwin ? pr : 0u;
+        const uint32_t i = p >> 2, sh = (p & 3u) * 8u;
+        const uint32_t d0 = L.window[i], d1 = L.window[i + 1], d2 = L.window[i + 2];
+        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh);  // bytes p .. p+3
+        const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, sh);  // bytes p+4 .. p+7
+        const bool two = (lo & 0x80u) != 0u;
+        const uint32_t hdr = two ? 2u : 1u;
+        const uint32_t h = two ? (lo & 0x7fu) | ((lo >> 1) & 0x3f80u) : lo & 0xffu;
+        const uint32_t cnt = h >> 1;
+        const bool isbp = (h & 1u) != 0u;
+        const uint32_t val = __builtin_amdgcn_alignbit(hi, lo, 8u * hdr) & hc.vbmask;
+        const uint32_t hend = p + hdr + (isbp ? 0u : hc.vb);
+        const uint32_t rend = p + hdr + (isbp ? __umul24(cnt, hc.w) : hc.vb);
+        const uint32_t nvals = isbp ? cnt * 8u : cnt;
+        const bool ok = inwin && (lo & 0x8080u) != 0x8080u && cnt != 0u && hend <= wl && (isbp || (val & ~hc.wmask) == 0u);
+        const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
+        const uint32_t lead = ~okmask != 0ull ? (uint32_t)__builtin_ctzll(~okmask) : (uint32_t)kWave;
+        // the run itself is not one for this loop (a long header, or — a pending run — a header the window
+        // no longer holds): the loops below take it
+        if (lead == 0u) break;
+        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+        if (first) {
+            // where in its run the walk stands
+            const uint32_t cnt0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+            const uint32_t hdr0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr);
+            const bool bp0 = __builtin_amdgcn_readfirstlane((int)(isbp ? 1u : 0u)) != 0;
+            bool fits;
+            if (st.pend == 0u) {
+                fits = p0 == st.o;
+            } else if (st.pend == 1u) {
+                fits = !bp0 && st.pcount <= cnt0 && st.o == p0 + hdr0 + hc.vb;
+                a = st.v - (cnt0 - st.pcount);
+            } else {
+                fits = bp0 && st.pcount <= cnt0 && st.o == p0 + hdr0 + (cnt0 - st.pcount) * hc.w && st.pskip < 8u;
+                a = st.v - (8u * (cnt0 - st.pcount) + st.pskip);
+            }
+            if (!fits || a > st.v) {
+                T.tn = 0;
+                return;  // st untouched
+            }
+            first = false;
+        } else if (p0 != o_cur) {
+            T.tn = 0;  // the table and the chain of runs part ways (never, for a table the scan of this stream wrote)
+            break;
+        }
+        o_cur = p0;
+        if (v + TILE > n) break;
+        const uint32_t tile_end = v + TILE;
+        const uint64_t leadmask = lead >= 64u ? ~0ull : (1ull << lead) - 1ull;
+        const uint32_t end_abs = a + wave_scan_u32(dn_select(leadmask, nvals));  // index behind the run's last value
+        const uint32_t start = end_abs - nvals;
+        const bool led = (uint32_t)lane < lead;
+        const bool intile = led && start < tile_end;
+        if (__builtin_amdgcn_ballot_w64(led && end_abs >= tile_end) == 0ull) break;  // 64 runs do not fill the tile
+        // the bytes of the run the tile reads
+        const uint32_t upto = min(end_abs, tile_end) - start;
+        const uint32_t need = isbp ? p + hdr + ((__umul24(upto, hc.w) + 7u) >> 3) : hend;
+        if (__builtin_amdgcn_ballot_w64(intile && need > wl) != 0ull) break;  // the window ends inside the tile
+        if (intile) {
+            const int32_t rs = (int32_t)(start - v);  // < 0: the run began in front of the tile
+            const uint32_t at = (p + hdr) * 8u;
+            L.pieces[lane] = make_uint2(isbp ? at - (uint32_t)__mul24(rs, (int32_t)hc.w) : at, isbp ? hc.w : 0u);
+            reinterpret_cast<uint8_t *>(L.marks)[rs > 0 ? (uint32_t)rs : 0u] = 1;
+        }
+        wave_sync();
+        dn_expand<MODE, OutT, Q, false, false>(L, sink, hc.wmask, posv, 0, 0, TILE, 0, v, lane, local_count, bad_index);
+        wave_sync();  // the marks were read; the next tile sets its own
+#pragma unroll
+        for (int q = 0; q < Q; ++q) L.marks[kWave * q + lane] = 0;
+        wave_sync();
+        // the runs that are out whole
+        const uint32_t u = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(led && end_abs <= tile_end));
+        if (u != 0u) {
+            a = (uint32_t)__builtin_amdgcn_readlane((int)end_abs, (int)(u - 1u));
+            o_cur = (uint32_t)__builtin_amdgcn_readlane((int)rend, (int)(u - 1u));
+        }
+        ti += u;
+        v = tile_end;
+    }
+    if (first) return;  // nothing done, st untouched
+    // ---- back to the terms of the other loops ----
+    T.ti = ti;
+    st.o = o_cur;
+    st.pend = 0;
+    st.pcount = 0;
+    st.pskip = 0;
+    if (a != v) {
+        // inside run ti: its header once more, on the scalar unit, then what is out of it
+        (void)hw_header_fast(st, L.window, wl, hc.w);  // a header this loop took: one or two bytes, all in the window
+        const uint32_t out = v - a;
+        if (st.pend == 1u) {
+            st.pcount -= out;
+        } else {
+            st.pskip = out & 7u;
+            st.pcount -= out >> 3;
+            st.o += (out >> 3) * hc.w;
+        }
+    }
+    st.v = v;
+}
+
 // Tiles of 256 Q values for as long as nothing needs the reference's checks.  On return the state
 // describes exactly what is out: st.v values, the next byte (or the pending run) at st.o.
 // allow_bulk = false: a fresh long bit-packed run is cut here like any other (the bulk path has just
 // declined it).
-template <int MODE, typename OutT, int Q>
+// TABLE: the caller may have a table of run headers (DnTable); without it none of that code exists.
+template <int MODE, typename OutT, int Q, bool TABLE>
 __device__ __forceinline__ uint32_t hw_dense_tiles(HybridWaveLds &L, HwState &st, const HwSink<OutT> &sink,
                                                    const HwConst &hc, uint32_t n, uint32_t mis, uint32_t wl,
                                                    uint32_t o_end, bool tail, uint32_t rw, bool allow_bulk, int lane,
@@ -436,6 +583,11 @@ __device__ __forceinline__ uint32_t hw_dense_tiles(HybridWaveLds &L, HwState &st
             for (int q = 0; q < Q; ++q)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) posv[q][k] = 4u * (uint32_t)lane + (uint32_t)(256 * q + k) - phase;
+        }
+        if (TABLE && T.tn != 0u && phase == 0u && st.v + TILE <= n && st.o < o_end && st.o < wl) {
+            hw_table_tiles<MODE, OutT, Q>(L, st, sink, hc, n, wl, lane, local_count, bad_index, T, c0, posv);
+            if (st.v >= n) return DN_DONE;
+            if (st.o >= o_end) return DN_WINDOW;
         }
         const uint32_t cap = TILE - phase;
         const uint32_t want = min(cap, n - st.v);
@@ -497,7 +649,7 @@ __device__ __forceinline__ uint32_t hw_dense_tiles(HybridWaveLds &L, HwState &st
                 uint32_t values;
                 DnNext nx;
                 uint32_t taken = kDnNoTable;
-                if (T.tn != 0u) taken = dn_span_table(L, st.o, wl, hc, want - fill, np, fill, phase, lane, values, nx, T, c0);
+                if (TABLE && T.tn != 0u) taken = dn_span_table(L, st.o, wl, hc, want - fill, np, fill, phase, lane, values, nx, T, c0);
                 if (taken == kDnNoTable)
                     taken = dn_span(L, st.o, wl, hc, want - fill, np, fill, phase, lane, values, nx, dense);
                 if (taken == kDnOdd) { reason = DN_GENERIC; break; }

@@ -461,7 +461,7 @@ namespace pq {
 // Modes as in hybrid_stream.  `dict` may point to LDS or global memory.  raw_groups != 0: the
 // stream has no run headers at all, it is that many bit-packed groups (PLAIN fixed-width values
 // are groups of width 32, BOOLEAN PLAIN bytes groups of width 1).
-template <int MODE, typename OutT>
+template <int MODE, typename OutT, bool TABLE = false>
 __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint8_t *S, int64_t len, uint32_t w,
                                                     uint32_t n, OutT *dst, const OutT *dict, uint32_t dict_len,
                                                     uint32_t max_level, int lane, uint32_t raw_groups = 0,
@@ -528,11 +528,11 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
     bool bad_index = false;    // DICT: a key outside the dictionary seen by this lane
     DnTable T;                 // where a walk in front of this decode found the run headers, if one was made
     T.tab = tab;
-    T.tn = tab != nullptr && tab_cache != nullptr ? tab_n : 0u;
+    T.tn = TABLE && tab != nullptr && tab_cache != nullptr ? tab_n : 0u;
     T.ti = 0;
     T.cache = tab_cache;
     T.cbase = 0;
-    if (T.tn != 0u) dn_table_fill(T, 0, lane);
+    if (TABLE && T.tn != 0u) dn_table_fill(T, 0, lane);
 
     while (true) {
         const int64_t c1 = c0 + kHwStride;
@@ -617,7 +617,7 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
         // ---- run-dense tiles: everything that needs none of the checks below ----
         if (vec_ok) {
             const bool allow_bulk = st.v != stuck_v;
-            const uint32_t why = hw_dense_tiles<MODE, OutT, MODE == HY_DICT ? kDnQuads : kDnQuadsPlain>(
+            const uint32_t why = hw_dense_tiles<MODE, OutT, MODE == HY_DICT ? kDnQuads : kDnQuadsPlain, TABLE>(
                 L, st, sink, hc, n, mis, wl, o_end, tail, rw, allow_bulk, lane, local_count, scount, bad_index, T,
                 (int32_t)c0);
             if (why == DN_DONE) { done = true; break; }
