@@ -144,12 +144,18 @@ __device__ __forceinline__ uint32_t dn_span(HybridWaveLds &L, uint32_t o, uint32
     const uint64_t untaken = chain & ~tmask;
     if (untaken != 0ull) {
         const uint32_t u = (uint32_t)__builtin_ctzll(untaken);
-        const uint32_t hu = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)u);
-        const uint32_t eu = (uint32_t)__builtin_amdgcn_readlane((int)hend, (int)u);
-        nx.kind = (hu & 1u) != 0u ? 2u : 1u;
-        nx.count = hu >> 1;
-        nx.value = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)u);
-        nx.o = eu;
+        if (values < room) {
+            const uint32_t hu = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)u);
+            const uint32_t eu = (uint32_t)__builtin_amdgcn_readlane((int)hend, (int)u);
+            nx.kind = (hu & 1u) != 0u ? 2u : 1u;
+            nx.count = hu >> 1;
+            nx.value = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)u);
+            nx.o = eu;
+        } else {
+            // the runs taken fill the room to the last value: this header is not read yet (the reference
+            // reads a header when it needs the run's first value; a pull may end right here)
+            nx.o = o + u;
+        }
     } else {
         nx.o = o + cur;
     }
@@ -266,8 +272,10 @@ __device__ __forceinline__ uint32_t dn_span_table(HybridWaveLds &L, uint32_t o, 
         nx.o = (uint32_t)__builtin_amdgcn_readlane((int)rend, (int)(taken - 1u));
     }
     uint32_t adv = taken;
-    if (taken < (uint32_t)kWave && ((okmask >> taken) & 1ull) != 0ull) {
-        // a well-formed run that does not fit (the tile, the window, the piece table): the caller cuts it
+    if (taken < (uint32_t)kWave && ((okmask >> taken) & 1ull) != 0ull && values < room) {
+        // a well-formed run that does not fit (the tile, the window, the piece table): the caller cuts it.
+        // Not when the runs taken fill the room to the last value: the reference reads a header when it
+        // needs the run's first value, and a pull that ends here has not read this one.
         const uint32_t hu = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)taken);
         nx.kind = (hu & 1u) != 0u ? 2u : 1u;
         nx.count = hu >> 1;

@@ -631,3 +631,90 @@ def test_spans_of_many_short_runs(ctx):
         ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 1024)
         ctx.set_option(K.OPT_SEGMENT_BYTES, 0)
 
+
+
+def _uleb(x):
+    out = []
+    while True:
+        b = x & 0x7F
+        x >>= 7
+        out.append(b | (0x80 if x else 0))
+        if not x:
+            return np.array(out, dtype=np.uint8)
+
+
+def _recipe_runs(rng, w, recipe, rounds):
+    """A hybrid stream put together from a recipe of (kind, count) pairs, repeated: "rle" runs of `count`
+    repeats (a header of three bytes from 8192 repeats on) and "bp" runs of `count` groups."""
+    vb = (w + 7) // 8
+    parts, values = [], []
+    for _ in range(rounds):
+        for kind, cnt in recipe:
+            cnt = int(cnt() if callable(cnt) else cnt)
+            if kind == "rle":
+                v = int(rng.integers(0, 1 << w))
+                parts += [_uleb(cnt << 1), np.frombuffer(v.to_bytes(vb, "little"), dtype=np.uint8)]
+                values.append(np.full(cnt, v, dtype=np.int64))
+            else:
+                vals = rng.integers(0, 1 << w, size=8 * cnt, dtype=np.int64)
+                parts += [_uleb((cnt << 1) | 1), synth.pack_bits(vals, w)]
+                values.append(vals)
+    return np.concatenate(parts).astype(np.uint8), np.concatenate(values)
+
+
+def test_segments_whose_run_headers_the_tiles_cannot_all_take(ctx):
+    """The decode of a segment takes the places of its run headers from the walk that proved the segment and
+    builds whole tiles from them; what such a tile cannot hold goes to the other loops and comes back: more
+    than 64 runs in a tile (runs of one and two repeats), headers of three bytes between short runs, bit-packed
+    runs long enough for the bulk path, a pull that ends inside a tile, in a run, at a run's first value."""
+    rng = np.random.default_rng(4242)
+    cases = []
+
+    def add(tag, kind, stream, n, **kw):
+        c = Case(kind, stream, n, **kw)
+        c.result_src_len = c.src.size
+        c.tag = tag
+        cases.append(c)
+
+    small = lambda: rng.integers(1, 3)
+    some = lambda: rng.integers(1, 30)
+    recipes = {
+        "ones and twos": ([("rle", small)], 60000),
+        "ones and twos between groups": ([("rle", small), ("rle", small), ("rle", small), ("bp", 1)], 15000),
+        "three-byte headers between short runs": ([("rle", some)] * 40 + [("rle", lambda: rng.integers(8192, 20000))] +
+                                                  [("bp", lambda: rng.integers(1, 4))] * 7, 120),
+        "bulk runs between short runs": ([("rle", some)] * 25 + [("bp", lambda: rng.integers(32, 200))] +
+                                         [("bp", 2), ("rle", some)] * 5, 150),
+        "two-byte headers": ([("rle", lambda: rng.integers(64, 400)), ("bp", lambda: rng.integers(1, 3))], 4000),
+    }
+    for name, (recipe, rounds) in recipes.items():
+        for w in (1, 2, 12):
+            s, vals = _recipe_runs(rng, w, recipe, rounds)
+            n = vals.size
+            st, want, _ = O.hybrid_decode(s, w, n, False)
+            assert st == O.OK and np.array_equal(want, vals)
+            for pull in (n, n - 1, n // 2, n // 2 + 1021, 1024 * (n // 3072), 1024 * (n // 3072) + 1):
+                add("hybrid w %d %s pull %d" % (w, name, pull), K.KIND_HYBRID, s, pull, bit_width=w)
+            add("hybrid w %d %s cut" % (w, name), K.KIND_HYBRID, s[: s.size * 3 // 5].copy(), n, bit_width=w)
+            if w <= 2:
+                lv = (1 << w) - 1
+                add("levels max %d %s" % (lv, name), K.KIND_LEVELS, s, n, max_def=lv)
+                add("levels max %d %s pull" % (lv, name), K.KIND_LEVELS, s, n // 2 + 7, max_def=lv)
+            if w == 1:
+                add("bool rle %s" % name, K.KIND_BOOL_RLE, synth.length_prefixed(s), n)
+            if w == 12:
+                d32 = rng.integers(-2**31, 2**31, size=4096, dtype=np.int64).astype(np.int32)
+                page = np.concatenate([[12], s]).astype(np.uint8)
+                add("dict w 12 %s" % name, K.KIND_DICT, page, n, dictionary=d32)
+                add("dict w 12 %s short dictionary" % name, K.KIND_DICT, page, n, dictionary=d32[:4090])
+    try:
+        for max_pages, sb in ((1 << 30, 2048), (1 << 30, 0), (0, 0)):
+            ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, max_pages)
+            ctx.set_option(K.OPT_SEGMENT_BYTES, sb)
+            _say("recipes: max_pages %d seg_bytes %d (%d cases)" % (max_pages, sb, len(cases)))
+            run_cases(ctx, cases, seed=9)
+            for c in cases:
+                _check_run_stream(c)
+    finally:
+        ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 1024)
+        ctx.set_option(K.OPT_SEGMENT_BYTES, 0)
