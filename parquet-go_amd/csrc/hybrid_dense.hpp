@@ -53,6 +53,56 @@ struct DnNext {
     uint32_t o;      // kind == 0: window offset of the next header; else: just behind the pending run's header (and value)
 };
 
+// The chain of run headers of a span from lane 0 on: chain = the lanes that hold real headers, cur = where
+// it leaves the span (>= 64) or the lane of the first byte on it that is no header.  ok: this lane's byte
+// parses as a simple header; nextlane: the lane its run ends in front of.
+__device__ __forceinline__ void dn_chain(bool ok, uint32_t nextlane, uint64_t okmask, bool dense, int lane,
+                                         uint64_t &chain, uint32_t &cur)
+{
+    if (dense) {
+        // Many short runs (RLE-dense streams: a run every three bytes): the chain by pointer doubling
+        // on the vector unit instead of a step per run.  Lane l keeps the set of byte positions the
+        // chain from l visits in 2^k steps and where it stands after them; five rounds cover the 32
+        // runs a span can hold at most (a run is two bytes or more).  ~60 instructions whatever the
+        // number of runs, against six a run below.
+        uint32_t J = ok ? min(nextlane, 64u) : 64u;  // 64: the chain from here has left the span or met no header
+        uint32_t mlo = lane < 32 ? 1u << lane : 0u, mhi = lane < 32 ? 0u : 1u << (lane - 32);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int at = (int)(J << 2);
+            const uint32_t glo = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)mlo);
+            const uint32_t ghi = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)mhi);
+            const uint32_t gj = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)J);
+            const bool on = J < 64u;
+            mlo |= on ? glo : 0u;
+            mhi |= on ? ghi : 0u;
+            J = on ? gj : 64u;
+        }
+        const uint64_t visited = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)mhi) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)mlo);
+        // the walk ends on a byte that is no header (it is visited, not on the chain), or behind the span
+        const uint32_t last = 63u - (uint32_t)__builtin_clzll(visited);
+        chain = visited & okmask;
+        cur = ((okmask >> last) & 1ull) != 0ull ? (uint32_t)__builtin_amdgcn_readlane((int)nextlane, (int)last) : last;
+    } else {
+        // five scalar instructions between the v_readlane that writes `cur` and the one that uses it as
+        // its lane select cover the wait states that dependency needs
+        asm volatile("s_mov_b64 %[chain], 0\n\t"
+                     "s_mov_b32 %[cur], 0\n"
+                     "1:\n\t"
+                     "s_bitcmp1_b64 %[ok], %[cur]\n\t"
+                     "s_cbranch_scc0 2f\n\t"
+                     "s_bitset1_b64 %[chain], %[cur]\n\t"
+                     "v_readlane_b32 %[cur], %[next], %[cur]\n\t"
+                     "s_cmp_lt_u32 %[cur], 64\n\t"
+                     "s_cbranch_scc1 1b\n"
+                     "2:"
+                     : [chain] "=&s"(chain), [cur] "=&s"(cur)
+                     : [ok] "s"(okmask), [next] "v"(nextlane)
+                     : "scc");
+    }
+}
+
 // Parse candidate headers at window offsets o .. o + 63, follow the chain of real ones from lane 0,
 // append the leading runs that lie wholly in the window and fit `room` values to the tile (each by
 // its own lane), describe what follows in nx.  Returns the number of runs appended, kDnOdd when the
@@ -83,48 +133,7 @@ __device__ __forceinline__ uint32_t dn_span(HybridWaveLds &L, uint32_t o, uint32
 
     uint32_t cur;
     uint64_t chain;
-    if (dense) {
-        // Many short runs (RLE-dense streams: a run every three bytes): the chain by pointer doubling
-        // on the vector unit instead of a step per run.  Lane l keeps the set of byte positions the
-        // chain from l visits in 2^k steps and where it stands after them; five rounds cover the 32
-        // runs a span can hold at most (a run is two bytes or more).  ~60 instructions whatever the
-        // number of runs, against six a run below.
-        uint32_t J = ok ? min(nextlane, 64u) : 64u;  // 64: the chain from here has left the span or met no header
-        uint32_t mlo = lane < 32 ? 1u << lane : 0u, mhi = lane < 32 ? 0u : 1u << (lane - 32);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int at = (int)(J << 2);
-            const uint32_t glo = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)mlo);
-            const uint32_t ghi = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)mhi);
-            const uint32_t gj = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)J);
-            const bool on = J < 64u;
-            mlo |= on ? glo : 0u;
-            mhi |= on ? ghi : 0u;
-            J = on ? gj : 64u;
-        }
-        const uint64_t visited = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)mhi) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)mlo);
-        // the walk ends on a byte that is no header (it is visited, not on the chain), or behind the span
-        const uint32_t last = 63u - (uint32_t)__builtin_clzll(visited);
-        chain = visited & okmask;
-        cur = ((okmask >> last) & 1ull) != 0ull ? (uint32_t)__builtin_amdgcn_readlane((int)nextlane, (int)last) : last;
-    } else {
-    // five scalar instructions between the v_readlane that writes `cur` and the one that uses it as
-    // its lane select cover the wait states that dependency needs
-    asm volatile("s_mov_b64 %[chain], 0\n\t"
-                 "s_mov_b32 %[cur], 0\n"
-                 "1:\n\t"
-                 "s_bitcmp1_b64 %[ok], %[cur]\n\t"
-                 "s_cbranch_scc0 2f\n\t"
-                 "s_bitset1_b64 %[chain], %[cur]\n\t"
-                 "v_readlane_b32 %[cur], %[next], %[cur]\n\t"
-                 "s_cmp_lt_u32 %[cur], 64\n\t"
-                 "s_cbranch_scc1 1b\n"
-                 "2:"
-                 : [chain] "=&s"(chain), [cur] "=&s"(cur)
-                 : [ok] "s"(okmask), [next] "v"(nextlane)
-                 : "scc");
-    }
+    dn_chain(ok, nextlane, okmask, dense, lane, chain, cur);
     dense = hc.w != 0u && (uint32_t)__builtin_popcountll(chain) >= kDnDenseRuns;
     values = 0;
     nx.kind = 0;
@@ -171,29 +180,33 @@ __device__ __forceinline__ uint32_t dn_span(HybridWaveLds &L, uint32_t o, uint32
 // The run headers of a stream as a walk in front of the decode found them (seghybrid.hip: the scan
 // of a segment notes the offset of every header it passes, 16 bits each, from the segment's first
 // header on).  The decode still reads every header itself; what the table saves is finding them.
+// Two sources: a table in memory, written by the scan of a segment in front of this decode (offsets from
+// the stream's first byte; kDnTabCache entries of it at a time in LDS), or the wave's own walk over the
+// window it is about to decode (hw_window_scan: window offsets, all of them in LDS, tab == nullptr).
 struct DnTable {
-    const uint16_t *tab;  // 16-byte aligned; nullptr: none
+    const uint16_t *tab;  // 16-byte aligned; nullptr: the entries in LDS are all there are
     uint32_t tn;          // entries; 0: none (or given up: the stream is not where the table says)
     uint32_t ti;          // entry of the next header, if the walk and the table are in step
-    uint16_t *cache;      // kDnTabCache entries of the table in LDS: [cbase, cbase + kDnTabCache)
+    uint16_t *cache;      // kDnTabCache entries in LDS: [cbase, cbase + kDnTabCache) of the table
     uint32_t cbase;       // a multiple of 8
 };
 constexpr uint32_t kDnNoTable = 0xfffffffeu;
-constexpr uint32_t kDnTabCache = 1024;  // entries: 16 per lane, two 16-byte loads
+enum DnTableMode : int { kTabNone = 0, kTabGiven = 1, kTabScan = 2 };
 
 __device__ __forceinline__ void dn_table_fill(DnTable &T, uint32_t base, int lane)
 {
     wave_sync();  // earlier reads of the cache are done
     const u32x4_t *src = reinterpret_cast<const u32x4_t *>(T.tab + base);
-    u32x4_t v[2];
+    constexpr uint32_t kLoads = kDnTabCache / (8u * (uint32_t)kWave);  // 16-byte loads a lane
+    u32x4_t v[kLoads];
 #pragma unroll
-    for (uint32_t k = 0; k < 2u; ++k) {
+    for (uint32_t k = 0; k < kLoads; ++k) {
         const uint32_t q = (uint32_t)lane + (uint32_t)kWave * k;
         v[k] = u32x4_t{0u, 0u, 0u, 0u};
         if (base + 8u * q < T.tn) v[k] = src[q];  // the table's room is whole 16-byte pieces
     }
 #pragma unroll
-    for (uint32_t k = 0; k < 2u; ++k) reinterpret_cast<u32x4_t *>(T.cache)[(uint32_t)lane + (uint32_t)kWave * k] = v[k];
+    for (uint32_t k = 0; k < kLoads; ++k) reinterpret_cast<u32x4_t *>(T.cache)[(uint32_t)lane + (uint32_t)kWave * k] = v[k];
     wave_sync();
     T.cbase = base;
 }
@@ -201,7 +214,7 @@ __device__ __forceinline__ void dn_table_fill(DnTable &T, uint32_t base, int lan
 // entry ti + lane, 0xffffffff behind the table's end
 __device__ __forceinline__ uint32_t dn_table_load(DnTable &T, uint32_t ti, int lane)
 {
-    if (ti < T.cbase || ti + (uint32_t)kWave > T.cbase + kDnTabCache) dn_table_fill(T, ti & ~7u, lane);
+    if (T.tab != nullptr && (ti < T.cbase || ti + (uint32_t)kWave > T.cbase + kDnTabCache)) dn_table_fill(T, ti & ~7u, lane);
     const uint32_t idx = ti + (uint32_t)lane;
     return idx < T.tn ? (uint32_t)T.cache[idx - T.cbase] : 0xffffffffu;
 }
@@ -418,6 +431,48 @@ __device__ __forceinline__ void dn_expand_const(const HwSink<OutT> &sink, uint32
     }
 }
 
+// The wave's own table: the chain of run headers of the window from window offset `from` on, as far as
+// it is made of simple headers (one or two bytes, the header and an RLE value inside the valid bytes),
+// up to the first header at or behind `stop` and at most cap entries.  Window offsets, ascending.
+// What the walk costs is a span parse per 64 bytes and six scalar instructions a run; what it saves is
+// every other piece of bookkeeping of the tiles that find their runs as they go.
+__device__ __forceinline__ uint32_t hw_window_scan(HybridWaveLds &L, uint32_t from, uint32_t stop, uint32_t wl,
+                                                   const HwConst &hc, uint16_t *tab, uint32_t cap, int lane)
+{
+    uint32_t o = from, tn = 0;
+    bool dense = false;  // the span in front held many runs: the next one's chain by pointer doubling
+    while (o < stop && tn + (uint32_t)kWave <= cap) {
+        const uint32_t p = o + (uint32_t)lane;
+        const uint32_t i = p >> 2, sh = (p & 3u) * 8u;
+        const uint32_t d0 = L.window[i], d1 = L.window[i + 1], d2 = L.window[i + 2];
+        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh);  // bytes p .. p+3
+        const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, sh);  // bytes p+4 .. p+7
+        const bool two = (lo & 0x80u) != 0u;
+        const uint32_t hdr = two ? 2u : 1u;
+        const uint32_t h = two ? (lo & 0x7fu) | ((lo >> 1) & 0x3f80u) : lo & 0xffu;
+        const uint32_t cnt = h >> 1;
+        const bool isbp = (h & 1u) != 0u;
+        const uint32_t val = __builtin_amdgcn_alignbit(hi, lo, 8u * hdr) & hc.vbmask;
+        const uint32_t hend = p + hdr + (isbp ? 0u : hc.vb);
+        const bool ok = (lo & 0x8080u) != 0x8080u && cnt != 0u && hend <= wl && (isbp || (val & ~hc.wmask) == 0u);
+        const uint32_t nextlane = (uint32_t)lane + hdr + (isbp ? __umul24(cnt, hc.w) : hc.vb);
+        const uint64_t okmask = __builtin_amdgcn_ballot_w64(ok);
+        uint32_t cur;
+        uint64_t chain;
+        dn_chain(ok, nextlane, okmask, dense, lane, chain, cur);
+        dense = (uint32_t)__builtin_popcountll(chain) >= kDnDenseRuns;
+        const uint32_t brel = stop - o;  // >= 1
+        const uint64_t in = brel < 64u ? chain & ~(~0ull << brel) : chain;
+        if (in == 0ull) break;
+        const uint32_t slot = tn + __builtin_amdgcn_mbcnt_hi((uint32_t)(in >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)in, 0u));
+        if (((in >> lane) & 1ull) != 0ull) tab[slot] = (uint16_t)p;
+        tn += (uint32_t)__builtin_popcountll(in);
+        if (in != chain || cur < 64u) break;  // the header at `stop`, or something the span parse does not take
+        o += cur;
+    }
+    return tn;
+}
+
 // Whole tiles straight from the table of run headers, for as long as the table, the window and the
 // tile agree: lane l parses run ti + l, a prefix sum of the runs' lengths says which of them reach
 // into the tile [v, v + 256 Q), each of those writes its own piece (a run the tile's first value lies
@@ -450,10 +505,7 @@ __device__ __forceinline__ void hw_table_tiles(HybridWaveLds &L, HwState &st, co
         }
         base += (uint32_t)kWave - 1u;  // all 64 lie in front: the last of them may be the one
     }
-    if (found == 0xffffffffu) {
-        T.tn = 0;
-        return;
-    }
+    if (found == 0xffffffffu) return;  // e.g. a pending run whose header an earlier window held: the loops below finish it
     uint32_t ti = found;        // the table entry of the run that holds value v (or starts with it)
     uint32_t v = st.v;
     uint32_t a = st.v;          // index of that run's first value
@@ -568,8 +620,10 @@ __device__ __forceinline__ void hw_table_tiles(HybridWaveLds &L, HwState &st, co
 // describes exactly what is out: st.v values, the next byte (or the pending run) at st.o.
 // allow_bulk = false: a fresh long bit-packed run is cut here like any other (the bulk path has just
 // declined it).
-// TABLE: the caller may have a table of run headers (DnTable); without it none of that code exists.
-template <int MODE, typename OutT, int Q, bool TABLE>
+// TABLE (DnTableMode): the caller may have a table of run headers (T; c0 = stream offset of window byte 0
+// where the table counts from the stream's first byte, 0 where it counts from the window's); kTabNone:
+// none of that code exists.
+template <int MODE, typename OutT, int Q, int TABLE>
 __device__ __forceinline__ uint32_t hw_dense_tiles(HybridWaveLds &L, HwState &st, const HwSink<OutT> &sink,
                                                    const HwConst &hc, uint32_t n, uint32_t mis, uint32_t wl,
                                                    uint32_t o_end, bool tail, uint32_t rw, bool allow_bulk, int lane,
@@ -592,7 +646,7 @@ __device__ __forceinline__ uint32_t hw_dense_tiles(HybridWaveLds &L, HwState &st
 #pragma unroll
                 for (int k = 0; k < 4; ++k) posv[q][k] = 4u * (uint32_t)lane + (uint32_t)(256 * q + k) - phase;
         }
-        if (TABLE && T.tn != 0u && phase == 0u && st.v + TILE <= n && st.o < o_end && st.o < wl) {
+        if (TABLE != kTabNone && T.tn != 0u && phase == 0u && st.v + TILE <= n && st.o < o_end && st.o < wl) {
             hw_table_tiles<MODE, OutT, Q>(L, st, sink, hc, n, wl, lane, local_count, bad_index, T, c0, posv);
             if (st.v >= n) return DN_DONE;
             if (st.o >= o_end) return DN_WINDOW;
@@ -657,7 +711,7 @@ __device__ __forceinline__ uint32_t hw_dense_tiles(HybridWaveLds &L, HwState &st
                 uint32_t values;
                 DnNext nx;
                 uint32_t taken = kDnNoTable;
-                if (TABLE && T.tn != 0u) taken = dn_span_table(L, st.o, wl, hc, want - fill, np, fill, phase, lane, values, nx, T, c0);
+                if (TABLE != kTabNone && T.tn != 0u) taken = dn_span_table(L, st.o, wl, hc, want - fill, np, fill, phase, lane, values, nx, T, c0);
                 if (taken == kDnNoTable)
                     taken = dn_span(L, st.o, wl, hc, want - fill, np, fill, phase, lane, values, nx, dense);
                 if (taken == kDnOdd) { reason = DN_GENERIC; break; }

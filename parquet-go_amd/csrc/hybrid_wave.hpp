@@ -30,6 +30,7 @@ constexpr int kHwSlack = 12;                    // zeroed words behind the windo
 constexpr int kHwConstWords = 4;                // behind them: RLE values of runs carried from tile to tile
 constexpr int kDnQuads = 4;                     // quads per lane and tile of the run-dense tiles: dictionary keys
 constexpr int kDnQuadsPlain = 4;                // ... values that are stored as they are (levels, booleans)
+constexpr uint32_t kDnTabCache = 1024;  // entries of a table of run headers a wave keeps in LDS: 16 per lane
 constexpr uint32_t kHwMaxBit = (uint32_t)(kHwChunk + 4 * kHwSlack - 8) * 8u;  // highest bit address a funnel read may use
 
 struct HybridWaveLds {
@@ -37,6 +38,7 @@ struct HybridWaveLds {
     uint32_t marks[kWave * kDnQuadsPlain];  // one byte per tile position: 1 = a piece starts here
     uint2 pieces[kWave];    // RLE piece: x = ~0, y = the value; bit-packed: x = 0, y = bit address of
                             // (virtual) tile position 0, so that position j sits at y + j * w
+    uint16_t tab[kDnTabCache];  // offsets of run headers: the window's, or a piece of a segment's table (hybrid_dense.hpp)
 };
 
 // wave_commit that also zeroes what lies past the end of the stream inside the last
@@ -461,12 +463,14 @@ namespace pq {
 // Modes as in hybrid_stream.  `dict` may point to LDS or global memory.  raw_groups != 0: the
 // stream has no run headers at all, it is that many bit-packed groups (PLAIN fixed-width values
 // are groups of width 32, BOOLEAN PLAIN bytes groups of width 1).
-template <int MODE, typename OutT, bool TABLE = false>
+// TABLE (DnTableMode): kTabGiven: tab[0 .. tab_n) holds the offsets of the stream's run headers, from the
+// stream's first byte, as a walk in front of this decode found them; kTabScan: the wave walks the headers of
+// every window it decodes run-dense tiles from itself.
+template <int MODE, typename OutT, int TABLE = 0>
 __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint8_t *S, int64_t len, uint32_t w,
                                                     uint32_t n, OutT *dst, const OutT *dict, uint32_t dict_len,
                                                     uint32_t max_level, int lane, uint32_t raw_groups = 0,
-                                                    const uint16_t *tab = nullptr, uint32_t tab_n = 0,
-                                                    uint16_t *tab_cache = nullptr)
+                                                    const uint16_t *tab = nullptr, uint32_t tab_n = 0)
 {
     HybridResult res{PQ_OK, 0, 0, 0};
     const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(dst) / sizeof(OutT)) & 3u);
@@ -527,12 +531,13 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
     uint32_t stuck_v = 0xffffffffu;  // st.v when the run-dense tiles last handed a run to the bulk path
     bool bad_index = false;    // DICT: a key outside the dictionary seen by this lane
     DnTable T;                 // where a walk in front of this decode found the run headers, if one was made
-    T.tab = tab;
-    T.tn = TABLE && tab != nullptr && tab_cache != nullptr ? tab_n : 0u;
+    T.tab = TABLE == kTabGiven ? tab : nullptr;
+    T.tn = TABLE == kTabGiven && tab != nullptr ? tab_n : 0u;
     T.ti = 0;
-    T.cache = tab_cache;
+    T.cache = L.tab;
     T.cbase = 0;
-    if (TABLE && T.tn != 0u) dn_table_fill(T, 0, lane);
+    if (TABLE == kTabGiven && T.tn != 0u) dn_table_fill(T, 0, lane);
+    bool scanned = false;      // kTabScan: this window's headers are in T
 
     while (true) {
         const int64_t c1 = c0 + kHwStride;
@@ -544,6 +549,10 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
         // a run header or a group may start at offsets below this one
         const uint32_t o_end = tail ? 0xffffffffu : (uint32_t)(kHwChunk - kHwGuard) + 1u;
         bool done = false;
+        if (TABLE == kTabScan) {
+            T.tn = 0;
+            scanned = false;
+        }
 
         while (true) {
         // ---- long bit-packed runs: whole tiles straight from the window, nothing through LDS ----
@@ -617,9 +626,28 @@ __device__ __forceinline__ HybridResult hybrid_wave(HybridWaveLds &L, const uint
         // ---- run-dense tiles: everything that needs none of the checks below ----
         if (vec_ok) {
             const bool allow_bulk = st.v != stuck_v;
+            // (not for streams of ten values and more a byte — long RLE runs —, whose tiles find a whole tile's
+            // runs in one or two spans as it is: BOOLEAN RLE at a mean run of 24 comes out 7 % slower with the walk)
+            if (TABLE == kTabScan && !scanned && (uint64_t)n <= 10ull * (uint64_t)len) {
+                // the headers of this window from the next one on, once, when the first run-dense tile is due
+                scanned = true;
+                const uint64_t from = st.pend == 2u ? (uint64_t)st.o + (uint64_t)st.pcount * w : (uint64_t)st.o;
+                const uint32_t stop = min(o_end, wl);
+                T.ti = 0;
+                T.tn = 0;
+                if (from < (uint64_t)stop) {
+                    // not where the next run is a bit-packed one of 32 groups and more: such streams are the
+                    // bulk path's, and what comes here of them are the odd ends of their runs
+                    const uint32_t f = (uint32_t)from;
+                    const uint32_t b0 = (uni(L.window[f >> 2]) >> ((f & 3u) * 8u)) & 0xffu;
+                    if (!(b0 < 0x80u && (b0 & 1u) != 0u && b0 >= 65u))
+                        T.tn = hw_window_scan(L, f, stop, wl, hc, L.tab, kDnTabCache, lane);
+                }
+                wave_sync();
+            }
             const uint32_t why = hw_dense_tiles<MODE, OutT, MODE == HY_DICT ? kDnQuads : kDnQuadsPlain, TABLE>(
                 L, st, sink, hc, n, mis, wl, o_end, tail, rw, allow_bulk, lane, local_count, scount, bad_index, T,
-                (int32_t)c0);
+                TABLE == kTabGiven ? (int32_t)c0 : 0);
             if (why == DN_DONE) { done = true; break; }
             if (why == DN_WINDOW) break;
             if (why == DN_BULK) { stuck_v = st.v; continue; }

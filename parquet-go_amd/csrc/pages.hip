@@ -601,7 +601,10 @@ __device__ __forceinline__ const uint32_t *wg_dict_for(const uint32_t *ldict, Di
     return have.bytes != 0u && want.bytes == have.bytes && want.off == have.off ? ldict : nullptr;
 }
 
-template <int MODE, typename OutT>
+// TAB (DnTableMode): whether the wave walks a window's run headers in front of its run-dense tiles.  The page
+// kernel does (nested pages are where such tiles are most of the work); the stream kernel does not: its
+// code for streams of long bit-packed runs comes out slower when the rest needs more registers.
+template <int MODE, typename OutT, int TAB = kTabNone>
 __device__ __forceinline__ HybridResult run_section_wave(HybridWaveLds &L, const Section &sec, uint32_t w, uint32_t n,
                                                          OutT *dst, const OutT *dict, uint32_t dict_len,
                                                          uint32_t max_level, int lane)
@@ -610,7 +613,7 @@ __device__ __forceinline__ HybridResult run_section_wave(HybridWaveLds &L, const
         HybridResult r{n > 0 ? PQ_NOT_INITIALIZED : PQ_OK, 0, 0, 0};
         return r;
     }
-    return hybrid_wave<MODE, OutT>(L, sec.S, sec.len, w, n, dst, dict, dict_len, max_level, lane);
+    return hybrid_wave<MODE, OutT, TAB>(L, sec.S, sec.len, w, n, dst, dict, dict_len, max_level, lane);
 }
 
 __device__ __forceinline__ HybridResult const_levels_wave(uint32_t *dst, uint32_t n, uint32_t max_level, int lane,
@@ -622,7 +625,7 @@ __device__ __forceinline__ HybridResult const_levels_wave(uint32_t *dst, uint32_
     return r;
 }
 
-template <typename OutT>
+template <typename OutT, int TAB = kTabNone>
 __device__ __forceinline__ HybridResult dict_values_wave(HybridWaveLds &L, const uint8_t *S, int64_t len, uint32_t n,
                                                          OutT *dst, WaveDict dict, uint32_t dict_len,
                                                          int32_t *init_status, int lane)
@@ -642,10 +645,10 @@ __device__ __forceinline__ HybridResult dict_values_wave(HybridWaveLds &L, const
     }
     *init_status = PQ_OK;
     if (dict.l)
-        r = hybrid_wave<HY_DICT, OutT>(L, S + 1, len - 1, w, n, dst, reinterpret_cast<const OutT *>(dict.l), dict_len,
+        r = hybrid_wave<HY_DICT, OutT, TAB>(L, S + 1, len - 1, w, n, dst, reinterpret_cast<const OutT *>(dict.l), dict_len,
                                        0, lane);
     else
-        r = hybrid_wave<HY_DICT, OutT>(L, S + 1, len - 1, w, n, dst, reinterpret_cast<const OutT *>(dict.g), dict_len,
+        r = hybrid_wave<HY_DICT, OutT, TAB>(L, S + 1, len - 1, w, n, dst, reinterpret_cast<const OutT *>(dict.g), dict_len,
                                        0, lane);
     r.consumed += 1;
     return r;
@@ -782,7 +785,8 @@ __global__ __launch_bounds__(kHwWG) void stream_wave_kernel(const pq_page_desc *
 }
 
 // A whole V1 / V2 data page by one wave: same order and error precedence as data_page_wg.
-__global__ __launch_bounds__(kHwWG) void data_wave_kernel(const pq_page_desc *__restrict__ descs,
+// 128 vector registers: four waves a SIMD, as before the table's code came in
+__global__ __launch_bounds__(kHwWG) __attribute__((amdgpu_waves_per_eu(4, 4))) void data_wave_kernel(const pq_page_desc *__restrict__ descs,
                                                         const uint32_t *__restrict__ ids, uint32_t count,
                                                         PageBuffers buf, pq_page_result *__restrict__ results,
                                                         uint32_t dict_lds_bytes, uint32_t *flag, uint32_t epoch)
@@ -873,13 +877,13 @@ __global__ __launch_bounds__(kHwWG) void data_wave_kernel(const pq_page_desc *__
         const bool zeros_out = (d.flags & PQ_FLAG_NO_LEVEL_OUTPUT) == 0u;
         // (the count of repetition levels equal to the maximum is never used: layout/page-v1.go:88-101)
         HybridResult rr = konst ? const_levels_wave(rep_dst, size, d.max_rep, lane, zeros_out)
-                                : run_section_wave<HY_RAW, uint32_t>(L, rep, wr, size, rep_dst, nullptr, 0, 0, lane);
+                                : run_section_wave<HY_RAW, uint32_t, kTabScan>(L, rep, wr, size, rep_dst, nullptr, 0, 0, lane);
         if (rr.status != PQ_OK) {
             lvl_status = rr.status;
             lvl_stage = PQ_STAGE_REP;
         } else {
             HybridResult dr = konst ? const_levels_wave(def_dst, size, d.max_def, lane, zeros_out)
-                                    : run_section_wave<HY_LEVELS, uint32_t>(L, def, wdw, size, def_dst, nullptr, 0,
+                                    : run_section_wave<HY_LEVELS, uint32_t, kTabScan>(L, def, wdw, size, def_dst, nullptr, 0,
                                                                              d.max_def, lane);
             if (dr.status != PQ_OK) {
                 lvl_status = dr.status;
@@ -900,10 +904,10 @@ __global__ __launch_bounds__(kHwWG) void data_wave_kernel(const pq_page_desc *__
         WaveDict wd{buf.dict + d.dict_off, ldict};
         HybridResult vr;
         if (d.elem_size == 8)
-            vr = dict_values_wave<uint64_t>(L, VS, vlen, nvals, reinterpret_cast<uint64_t *>(buf.values + d.dst_off), wd,
+            vr = dict_values_wave<uint64_t, kTabScan>(L, VS, vlen, nvals, reinterpret_cast<uint64_t *>(buf.values + d.dst_off), wd,
                                             d.dict_len, &v_init, lane);
         else
-            vr = dict_values_wave<uint32_t>(L, VS, vlen, nvals, reinterpret_cast<uint32_t *>(buf.values + d.dst_off), wd,
+            vr = dict_values_wave<uint32_t, kTabScan>(L, VS, vlen, nvals, reinterpret_cast<uint32_t *>(buf.values + d.dst_off), wd,
                                             d.dict_len, &v_init, lane);
         v_status = vr.status;
         v_count = vr.n_decoded;
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(kHwWG) void data_wave_kernel(const pq_page_desc *__
         const Section sec = section_init_size(VS, vlen, 1u);
         v_init = sec.init_status;
         if (v_init == PQ_OK) {
-            const HybridResult vr = run_section_wave<HY_RAW, uint32_t>(
+            const HybridResult vr = run_section_wave<HY_RAW, uint32_t, kTabScan>(
                 L, sec, 1u, nvals, reinterpret_cast<uint32_t *>(buf.values + d.dst_off), nullptr, 0, 0, lane);
             v_status = vr.status;
             v_count = vr.n_decoded;

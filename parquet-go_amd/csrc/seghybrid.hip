@@ -591,29 +591,25 @@ __global__ __launch_bounds__(kWG) void lseg_link_kernel(const pq_page_desc *__re
 
 // ---- decode ---------------------------------------------------------------------------------------
 
-// LDS of the decode kernel: a HybridWaveLds and a piece of the run-header table per wave, the dictionary behind
-constexpr uint32_t hs_lds_fixed(int waves)
-{
-    return hs_align16((uint32_t)sizeof(HybridWaveLds) * (uint32_t)waves) +
-           (uint32_t)waves * kDnTabCache * (uint32_t)sizeof(uint16_t);
-}
+// LDS of the decode kernel: a HybridWaveLds per wave, the dictionary behind
+constexpr uint32_t hs_lds_fixed(int waves) { return hs_align16((uint32_t)sizeof(HybridWaveLds) * (uint32_t)waves); }
 
 template <typename OutT>
 __device__ __forceinline__ HybridResult hseg_values(HybridWaveLds &L, uint32_t kind_mode, const uint8_t *S, int64_t len,
                                                     uint32_t w, uint32_t n, uint8_t *dst, const uint8_t *gdict,
                                                     const uint32_t *ldict, uint32_t dict_len, uint32_t max_level,
-                                                    int lane, const uint16_t *tab, uint32_t runs, uint16_t *tcache)
+                                                    int lane, const uint16_t *tab, uint32_t runs)
 {
     if (kind_mode == HY_DICT) {
         const OutT *dict = ldict ? reinterpret_cast<const OutT *>(ldict) : reinterpret_cast<const OutT *>(gdict);
-        return hybrid_wave<HY_DICT, OutT, true>(L, S, len, w, n, reinterpret_cast<OutT *>(dst), dict, dict_len, 0, lane, 0, tab,
-                                          runs, tcache);
+        return hybrid_wave<HY_DICT, OutT, kTabGiven>(L, S, len, w, n, reinterpret_cast<OutT *>(dst), dict, dict_len, 0, lane, 0, tab,
+                                                     runs);
     }
     if (kind_mode == HY_LEVELS)
-        return hybrid_wave<HY_LEVELS, uint32_t, true>(L, S, len, w, n, reinterpret_cast<uint32_t *>(dst), nullptr, 0, max_level,
-                                                lane, 0, tab, runs, tcache);
-    return hybrid_wave<HY_RAW, uint32_t, true>(L, S, len, w, n, reinterpret_cast<uint32_t *>(dst), nullptr, 0, 0, lane, 0, tab,
-                                         runs, tcache);
+        return hybrid_wave<HY_LEVELS, uint32_t, kTabGiven>(L, S, len, w, n, reinterpret_cast<uint32_t *>(dst), nullptr, 0, max_level,
+                                                           lane, 0, tab, runs);
+    return hybrid_wave<HY_RAW, uint32_t, kTabGiven>(L, S, len, w, n, reinterpret_cast<uint32_t *>(dst), nullptr, 0, 0, lane, 0, tab,
+                                                    runs);
 }
 
 // 128 vector registers: four waves a SIMD, as before the table's code came in
@@ -627,7 +623,6 @@ __global__ __launch_bounds__(kHsWaves * kWave) __attribute__((amdgpu_waves_per_e
 {
     HybridWaveLds *LW = reinterpret_cast<HybridWaveLds *>(pq_hs_smem);
     // the workgroup's LDS copy of a dictionary: the one its first segment's page reads, if it fits
-    uint16_t *tcaches = reinterpret_cast<uint16_t *>(pq_hs_smem + hs_align16((uint32_t)sizeof(HybridWaveLds) * kHsWaves));
     uint32_t *ld = reinterpret_cast<uint32_t *>(pq_hs_smem + hs_lds_fixed(kHsWaves));
     uint64_t have_off = 0;
     uint32_t have_bytes = 0;
@@ -672,9 +667,9 @@ __global__ __launch_bounds__(kHsWaves * kWave) __attribute__((amdgpu_waves_per_e
     HybridResult r{PQ_OK, 0, 0, 0};
     if (count != 0u || flags == kSegTail)
         r = es == 8u ? hseg_values<uint64_t>(L, pg.kind_mode, S + off, slen, pg.w, count, sdst, gdict, ldict, d.dict_len,
-                                             pg.max_level, lane, tab, runs, tcaches + kDnTabCache * (uint32_t)wave)
+                                             pg.max_level, lane, tab, runs)
                      : hseg_values<uint32_t>(L, pg.kind_mode, S + off, slen, pg.w, count, sdst, gdict, ldict, d.dict_len,
-                                             pg.max_level, lane, tab, runs, tcaches + kDnTabCache * (uint32_t)wave);
+                                             pg.max_level, lane, tab, runs);
     if (lane == 0) {
         recs[g].status = r.status;
         recs[g].n_decoded = r.n_decoded;
