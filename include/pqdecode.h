@@ -122,8 +122,11 @@ int pq_ctx_synchronize(pq_ctx *ctx);
  * in segments of about 8192 values).  Data pages of nested columns (max_rep != 0) with 65 536
  * slots and more run as three such units, repetition levels, definition levels and values, which
  * the V1 length prefixes and V2 header lengths tell apart before anything is decoded
- * (layout/page-v1.go:69-77, layout/page-v2.go:110-126).  Default 1024; 0 = never.  Results are the
- * same either way.
+ * (layout/page-v1.go:69-77, layout/page-v2.go:110-126).  A plan that cuts streams of runs of any kind
+ * keeps, in its device block, two bytes of table per two bytes of such a stream's segments (about twice
+ * the streams' size; the walk that proves a segment leaves the places of its run headers there for the
+ * decode); plans for which that would be more than 2 GiB keep none and decode a little slower.
+ * Default 1024; 0 = never.  Results are the same either way.
  * PQ_OPT_SEGMENT_BYTES: bytes of the stream per segment, a multiple of 16 from 2048 on; 0 (the
  * default) = chosen from the plan's size, 8 to 64 KiB.  Pages shorter than three segments are not
  * cut.  Both options apply to plans created after the call. */
