@@ -44,7 +44,9 @@ namespace pq {
 // workgroups are small: 64 level streams of 1 M slots 0.30 -> 0.27 ms).
 constexpr int kHsWavesDict = 8, kHsWavesPlain = 4;
 constexpr uint32_t kHsMinStride = 64;    // shorter runs are not worth a lane each
-constexpr uint32_t kLsPreRoll = 512;     // bytes in front of a segment a scan starts at
+constexpr uint32_t kLsPreRoll = 512;     // bytes in front of a segment a scan starts at; half of it at width 1, where
+                                         // it holds as many runs (measured: 256 bytes cost definition levels and
+                                         // 12-bit keys a third in repairs, and gain one-bit streams 4 %)
 constexpr uint32_t kLsGuard = 80;        // a span parse reads 64 + 12 bytes from its first byte on
 constexpr uint32_t kLsRepairs = 1024;    // broken links per page the link pass walks again itself (a walk costs a
                                          // tenth of a decode: still far better than leaving the rest to the tail)
@@ -446,7 +448,8 @@ __global__ __launch_bounds__(kWG) void lseg_scan_kernel(const pq_page_desc *__re
             // from an arbitrary byte in front of the segment: by the time the walk reaches the
             // segment it has, as a rule, fallen into step with the real chain; whatever it runs
             // into that is no run header makes it start again one byte further on
-            uint32_t o = max(pg.pos0, lo > kLsPreRoll ? lo - kLsPreRoll : 0u);
+            const uint32_t pre = pg.w == 1u ? kLsPreRoll / 2u : kLsPreRoll;
+            uint32_t o = max(pg.pos0, lo > pre ? lo - pre : 0u);
             uint64_t unused = 0;
             entry = lo;
             for (uint32_t tries = 0; tries <= kLsPreRoll; ++tries) {  // each try starts at least a byte further on
