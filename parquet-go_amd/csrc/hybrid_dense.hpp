@@ -320,7 +320,8 @@ __device__ __forceinline__ uint32_t dn_read(const uint32_t *lds, uint32_t bit)
 template <int MODE, typename OutT, int Q, bool RAGGED, bool SOLO>
 __device__ __forceinline__ void dn_expand(HybridWaveLds &L, const HwSink<OutT> &sink, uint32_t wmask,
                                           const uint32_t (&posv)[Q][4], uint32_t y0, uint32_t s0, uint32_t clip,
-                                          uint32_t phase, uint32_t v, int lane, uint32_t &local_count, bool &bad_index)
+                                          uint32_t phase, uint32_t v, int lane, uint32_t &local_count, uint32_t &scount,
+                                          bool &bad_index)
 {
     uint32_t key[Q][4];
     if (SOLO) {
@@ -376,8 +377,11 @@ __device__ __forceinline__ void dn_expand(HybridWaveLds &L, const HwSink<OutT> &
 #pragma unroll
                 for (int k = 0; k < 4; ++k) out[k] = (OutT)key[q][k];
                 if (MODE == HY_LEVELS) {
+                    // counted on the scalar unit (a compare, a bit count, an addition): the vector unit is
+                    // the busy one here
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) local_count += key[q][k] == sink.max_level ? 1u : 0u;
+                    for (int k = 0; k < 4; ++k)
+                        scount += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(key[q][k] == sink.max_level));
                 }
             }
             hw_store4<OutT>(qp0 + 256 * q, out, 0xfu, true);
@@ -486,8 +490,8 @@ __device__ __forceinline__ uint32_t hw_window_scan(HybridWaveLds &L, uint32_t fr
 template <int MODE, typename OutT, int Q>
 __device__ __forceinline__ void hw_table_tiles(HybridWaveLds &L, HwState &st, const HwSink<OutT> &sink,
                                                const HwConst &hc, uint32_t n, uint32_t wl, int lane,
-                                               uint32_t &local_count, bool &bad_index, DnTable &T, int32_t c0,
-                                               const uint32_t (&posv)[Q][4])
+                                               uint32_t &local_count, uint32_t &scount, bool &bad_index, DnTable &T,
+                                               int32_t c0, const uint32_t (&posv)[Q][4])
 {
     constexpr uint32_t TILE = 256u * Q;
     // ---- the run the walk stands at or in: the last header in front of `probe` ----
@@ -580,7 +584,7 @@ __device__ __forceinline__ void hw_table_tiles(HybridWaveLds &L, HwState &st, co
             reinterpret_cast<uint8_t *>(L.marks)[rs > 0 ? (uint32_t)rs : 0u] = 1;
         }
         wave_sync();
-        dn_expand<MODE, OutT, Q, false, false>(L, sink, hc.wmask, posv, 0, 0, TILE, 0, v, lane, local_count, bad_index);
+        dn_expand<MODE, OutT, Q, false, false>(L, sink, hc.wmask, posv, 0, 0, TILE, 0, v, lane, local_count, scount, bad_index);
         wave_sync();  // the marks were read; the next tile sets its own
 #pragma unroll
         for (int q = 0; q < Q; ++q) L.marks[kWave * q + lane] = 0;
@@ -647,7 +651,7 @@ __device__ __forceinline__ uint32_t hw_dense_tiles(HybridWaveLds &L, HwState &st
                 for (int k = 0; k < 4; ++k) posv[q][k] = 4u * (uint32_t)lane + (uint32_t)(256 * q + k) - phase;
         }
         if (TABLE != kTabNone && T.tn != 0u && phase == 0u && st.v + TILE <= n && st.o < o_end && st.o < wl) {
-            hw_table_tiles<MODE, OutT, Q>(L, st, sink, hc, n, wl, lane, local_count, bad_index, T, c0, posv);
+            hw_table_tiles<MODE, OutT, Q>(L, st, sink, hc, n, wl, lane, local_count, scount, bad_index, T, c0, posv);
             if (st.v >= n) return DN_DONE;
             if (st.o >= o_end) return DN_WINDOW;
         }
@@ -738,17 +742,17 @@ __device__ __forceinline__ uint32_t hw_dense_tiles(HybridWaveLds &L, HwState &st
                     dn_expand_const<MODE, OutT, Q>(sink, key, posv, clip, phase, st.v, lane, scount, bad_index);
                 } else if (full) {
                     dn_expand<MODE, OutT, Q, false, true>(L, sink, hc.wmask, posv, y0, s0, clip, phase, st.v, lane,
-                                                          local_count, bad_index);
+                                                          local_count, scount, bad_index);
                 } else {
                     dn_expand<MODE, OutT, Q, true, true>(L, sink, hc.wmask, posv, y0, s0, clip, phase, st.v, lane,
-                                                         local_count, bad_index);
+                                                         local_count, scount, bad_index);
                 }
             } else if (full) {
                 dn_expand<MODE, OutT, Q, false, false>(L, sink, hc.wmask, posv, 0, 0, clip, phase, st.v, lane, local_count,
-                                                       bad_index);
+                                                       scount, bad_index);
             } else {
                 dn_expand<MODE, OutT, Q, true, false>(L, sink, hc.wmask, posv, 0, 0, clip, phase, st.v, lane, local_count,
-                                                      bad_index);
+                                                      scount, bad_index);
             }
             wave_sync();  // the marks were read; the next tile sets its own
 #pragma unroll
