@@ -148,6 +148,11 @@ int pq_ctx_synchronize(pq_ctx *ctx);
  * the work behind it: nothing changes for the caller but the time.  0: one after the other on the
  * context's stream.  Never used while the context's stream is being captured into a graph. */
 #define PQ_OPT_CONCURRENT_GROUPS 7
+/* PQ_OPT_RUN_TABLES: 1 (the default): a plan that cuts hybrid streams of runs of any kind into segments keeps
+ * the table of run-header offsets described under PQ_OPT_SEGMENT_MAX_PAGES; 0: plans created from now on keep
+ * none (their device block is smaller by about twice those streams' bytes, their segments' decode finds the
+ * run headers itself, about a third slower).  Results are the same either way. */
+#define PQ_OPT_RUN_TABLES 8
 int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value);
 const char *pq_status_string(int status);
 const char *pq_last_error(pq_ctx *ctx); /* text of the last HIP failure on ctx */

@@ -31,6 +31,7 @@ OPT_SEGMENT_BYTES = 4
 OPT_CHUNK_SLOTS = 5
 OPT_SEGMENT_SPIN_LIMIT = 6
 OPT_CONCURRENT_GROUPS = 7
+OPT_RUN_TABLES = 8
 
 STAGE_NONE, STAGE_REP_INIT, STAGE_DEF_INIT, STAGE_VALUES_INIT, STAGE_REP, STAGE_DEF, STAGE_VALUES = range(7)
 

@@ -56,6 +56,7 @@ struct pq_ctx {
     // plans whose groups are large enough run them side by side: up to three streams next to the
     // context's own, forked from it and joined to it with events (PQ_OPT_CONCURRENT_GROUPS)
     bool concurrent_groups = true;
+    bool run_tables = true;  // PQ_OPT_RUN_TABLES
     hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t lane_fork = nullptr, lane_join[3] = {nullptr, nullptr, nullptr};
 };
@@ -461,6 +462,10 @@ int pq_ctx_set_option(pq_ctx *ctx, int option, int64_t value)
         if (value != 0 && value != 1) return PQ_ERR_BAD_ARGUMENT;
         ctx->concurrent_groups = value != 0;
         return PQ_OK;
+    case PQ_OPT_RUN_TABLES:
+        if (value != 0 && value != 1) return PQ_ERR_BAD_ARGUMENT;
+        ctx->run_tables = value != 0;
+        return PQ_OK;
     case PQ_OPT_SEGMENT_SPIN_LIMIT:
         if (value < 0) return PQ_ERR_BAD_ARGUMENT;
         ctx->seg_spin_limit = value > 0xffffffffll ? 0xffffffffu : (uint32_t)value;
@@ -800,7 +805,7 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
     build_hseg(ids[0], hsh[0], false);
     build_hseg(ids[6], hsh[1], true);
     for (HsegHost &h : hsh)
-        if (h.tab_entries * sizeof(uint16_t) > kHsegTableMax) {  // too much to keep: the decode finds the headers itself
+        if (!ctx->run_tables || h.tab_entries * sizeof(uint16_t) > kHsegTableMax) {  // none wanted, or too much to keep: the decode finds the headers itself
             h.tab_entries = 0;
             for (pq::HsegPage &pg : h.pages) pg.tab_first = 0xffffffffu;
         }
@@ -1417,6 +1422,7 @@ int pq_decode_chunks(pq_ctx *ctx, pq_chunk_job *jobs, size_t n_jobs, uint32_t fl
         sl.sub->seg_max_pages = ctx->seg_max_pages;
         sl.sub->seg_bytes = ctx->seg_bytes;
         sl.sub->seg_spin_limit = ctx->seg_spin_limit;
+        sl.sub->run_tables = ctx->run_tables;
         if (!sl.done) PQ_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         if (!sl.copied_in) PQ_HIP(ctx, hipEventCreateWithFlags(&sl.copied_in, hipEventDisableTiming));
         if (!sl.decoded) PQ_HIP(ctx, hipEventCreateWithFlags(&sl.decoded, hipEventDisableTiming));

@@ -543,21 +543,24 @@ def test_run_streams_in_segments_vs_oracle(ctx, seg_bytes):
     for c in cases:                             # one plan per family of cases
         families.setdefault(" ".join(c.tag.split()[:2]), []).append(c)
     try:
-        for max_pages in (0, 1 << 30):          # not cut at all, and cut into segments
+        # not cut at all; cut into segments; cut, the decode finding the run headers itself (no table of them)
+        for max_pages, tables in ((0, 1), (1 << 30, 1), (1 << 30, 0)):
             ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, max_pages)
             ctx.set_option(K.OPT_SEGMENT_BYTES, seg_bytes)
+            ctx.set_option(K.OPT_RUN_TABLES, tables)
             for name, group in families.items():
-                _say("run streams: seg_bytes %d, max_pages %d, %s (%d cases)" % (seg_bytes, max_pages, name, len(group)))
+                _say("run streams: seg_bytes %d, max_pages %d, tables %d, %s (%d cases)" % (seg_bytes, max_pages, tables, name, len(group)))
                 run_cases(ctx, group, seed=13)
                 for c in group:
                     _check_run_stream(c)
-            _say("run streams: seg_bytes %d, max_pages %d, all in one plan" % (seg_bytes, max_pages))
+            _say("run streams: seg_bytes %d, max_pages %d, tables %d, all in one plan" % (seg_bytes, max_pages, tables))
             run_cases(ctx, cases, seed=13)
             for c in cases:
                 _check_run_stream(c)
     finally:
         ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 1024)
         ctx.set_option(K.OPT_SEGMENT_BYTES, 0)
+        ctx.set_option(K.OPT_RUN_TABLES, 1)
 
 
 def _hand_runs(rng, w, n_runs, rle_share, kinds=("rle8", "bp1")):
@@ -708,13 +711,16 @@ def test_segments_whose_run_headers_the_tiles_cannot_all_take(ctx):
                 add("dict w 12 %s" % name, K.KIND_DICT, page, n, dictionary=d32)
                 add("dict w 12 %s short dictionary" % name, K.KIND_DICT, page, n, dictionary=d32[:4090])
     try:
-        for max_pages, sb in ((1 << 30, 2048), (1 << 30, 0), (0, 0)):
+        # cut with and without the table of run headers (PQ_OPT_RUN_TABLES), cut at the default length, not cut
+        for max_pages, sb, tables in ((1 << 30, 2048, 1), (1 << 30, 2048, 0), (1 << 30, 0, 1), (0, 0, 1)):
             ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, max_pages)
             ctx.set_option(K.OPT_SEGMENT_BYTES, sb)
-            _say("recipes: max_pages %d seg_bytes %d (%d cases)" % (max_pages, sb, len(cases)))
+            ctx.set_option(K.OPT_RUN_TABLES, tables)
+            _say("recipes: max_pages %d seg_bytes %d tables %d (%d cases)" % (max_pages, sb, tables, len(cases)))
             run_cases(ctx, cases, seed=9)
             for c in cases:
                 _check_run_stream(c)
     finally:
         ctx.set_option(K.OPT_SEGMENT_MAX_PAGES, 1024)
         ctx.set_option(K.OPT_SEGMENT_BYTES, 0)
+        ctx.set_option(K.OPT_RUN_TABLES, 1)
