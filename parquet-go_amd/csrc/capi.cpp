@@ -116,6 +116,7 @@ struct pq_plan {
         pq::HsegRec *d_recs = nullptr;
         pq::HsegScan *d_scans = nullptr;  // two records per segment
         uint16_t *d_tabs = nullptr;       // run-header offsets the scans leave for the decode (HsegPage::tab_first)
+        int fix_rounds = 2;               // 1: every stream is one of narrow values (levels, booleans)
     } hs[2];
     // large pages of nested columns run as three units each (nested.hip): the internal table holds
     // n_total = n + 2 * n_split descriptors and results, the caller sees the first n
@@ -750,6 +751,7 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
         std::vector<pq::HsegPage> pages;
         std::vector<uint32_t> seg_owner, check_owner;
         uint64_t tab_entries = 0;  // 16-bit entries of the run-header table, a multiple of 8 per page
+        bool narrow = true;        // every cut stream holds values of at most 3 bits (as far as the descriptor tells)
     } hsh[2];
     auto build_hseg = [&](std::vector<uint32_t> &g, HsegHost &out, bool units) {
         if (g.empty() || (!units && g.size() >= ctx->seg_max_pages)) return;
@@ -797,6 +799,12 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
             // per two bytes of stream the segments can hold
             pg.tab_first = (uint32_t)(out.tab_entries / 8u);
             out.tab_entries += ((uint64_t)pg.n_segs * (pg.seg_bytes / 2u) + 7u) & ~7ull;
+            {
+                const pq_page_desc &d = descs[i];
+                const bool few_bits = d.kind == PQ_KIND_BOOL_RLE || (d.kind == PQ_KIND_LEVELS && d.max_def < 8u) ||
+                                      (d.kind == PQ_KIND_HYBRID && d.bit_width <= 3u);
+                out.narrow = out.narrow && few_bits;
+            }
             out.seg_owner.insert(out.seg_owner.end(), pg.n_segs, (uint32_t)out.pages.size());
             out.check_owner.insert(out.check_owner.end(), pg.n_checks, (uint32_t)out.pages.size());
             out.pages.push_back(pg);
@@ -813,6 +821,7 @@ static int plan_create(pq_ctx *ctx, const pq_page_desc *user_descs, size_t n_pag
         plan->hs[k].n_pages = (uint32_t)hsh[k].pages.size();
         plan->hs[k].n_segs = (uint32_t)hsh[k].seg_owner.size();
         plan->hs[k].n_checks = (uint32_t)hsh[k].check_owner.size();
+        plan->hs[k].fix_rounds = hsh[k].narrow ? 1 : 2;
     }
     std::vector<uint32_t> all;
     all.reserve(n_total);
@@ -1015,7 +1024,7 @@ static int plan_launch(pq_plan *plan, pq::PageBuffers buf)
         return pq::launch_seg_hybrid(ctx->stream, plan->d_descs, hd.d_pages, hd.n_pages, hd.d_check_owner, hd.n_checks,
                                      hd.d_counts, hd.d_seg_owner, hd.n_segs, hd.d_recs, hd.d_scans, buf, plan->d_results,
                                      &hd == &plan->hs[1] ? 0u : plan->dict_lds_bytes,  // level units read no dictionary
-                                     hd.d_tabs);
+                                     hd.d_tabs, hd.fix_rounds);
     };
     if (plan->n_split != 0) {
         // large nested pages: where their three sections lie, then the level units; the values run
@@ -1059,7 +1068,7 @@ static int plan_launch(pq_plan *plan, pq::PageBuffers buf)
         return pq::launch_seg_hybrid(st, plan->d_descs, hd.d_pages, hd.n_pages, hd.d_check_owner, hd.n_checks, hd.d_counts,
                                      hd.d_seg_owner, hd.n_segs, hd.d_recs, hd.d_scans, buf, plan->d_results,
                                      &hd == &plan->hs[1] ? 0u : plan->dict_lds_bytes,  // level units read no dictionary
-                                     hd.d_tabs);
+                                     hd.d_tabs, hd.fix_rounds);
     };
     PQ_HIP(ctx, seg_hybrid0(lane[0]));
     PQ_HIP(ctx, pq::launch_stream_pages(lane[0], plan->d_descs, plan->d_ids + plan->first[0], plan->count[0], buf,

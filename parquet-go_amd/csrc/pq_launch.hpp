@@ -172,11 +172,13 @@ struct HsegScan {
                      // table: all of its runs, or 0
 };
 // d_check_owner / d_seg_owner: counter -> page and segment -> page maps.  d_scans: 2 * n_segs records.
-// d_tabs: the run-header table HsegPage::tab_first points into, or nullptr.
+// d_tabs: the run-header table HsegPage::tab_first points into, or nullptr.  fix_rounds: 1 or 2 rounds of
+// re-walking segments entered at the wrong place in front of the pass that links them.
 hipError_t launch_seg_hybrid(hipStream_t s, const pq_page_desc *d_descs, HsegPage *d_pages, uint32_t n_pages,
                              const uint32_t *d_check_owner, uint32_t n_checks, uint32_t *d_counts,
                              const uint32_t *d_seg_owner, uint32_t n_segs, HsegRec *d_recs, HsegScan *d_scans,
-                             PageBuffers buf, pq_page_result *d_results, uint32_t dict_lds_bytes, uint16_t *d_tabs);
+                             PageBuffers buf, pq_page_result *d_results, uint32_t dict_lds_bytes, uint16_t *d_tabs,
+                             int fix_rounds);
 
 // ---- large nested pages as three units (nested.hip) ---------------------------------------------
 // The host fills the first nine fields; the rest is written on the device every run.

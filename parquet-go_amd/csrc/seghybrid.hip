@@ -728,7 +728,8 @@ __global__ __launch_bounds__(kWG) void hseg_final_kernel(const HsegPage *__restr
 hipError_t launch_seg_hybrid(hipStream_t s, const pq_page_desc *d_descs, HsegPage *d_pages, uint32_t n_pages,
                              const uint32_t *d_check_owner, uint32_t n_checks, uint32_t *d_counts,
                              const uint32_t *d_seg_owner, uint32_t n_segs, HsegRec *d_recs, HsegScan *d_scans,
-                             PageBuffers buf, pq_page_result *d_results, uint32_t dict_lds_bytes, uint16_t *d_tabs)
+                             PageBuffers buf, pq_page_result *d_results, uint32_t dict_lds_bytes, uint16_t *d_tabs,
+                             int fix_rounds)
 {
     if (n_pages == 0 || n_segs == 0) return hipSuccess;
     const uint32_t per = kWG / kWave;
@@ -741,14 +742,21 @@ hipError_t launch_seg_hybrid(hipStream_t s, const pq_page_desc *d_descs, HsegPag
     hipLaunchKernelGGL(hseg_link_kernel, gp, dim3(kWG), 0, s, d_descs, d_pages, n_pages, d_counts, d_recs);
     // d_scans: two arrays of n_segs records, the second the first after the fix pass
     hipLaunchKernelGGL(lseg_scan_kernel, gs, dim3(kWG), 0, s, d_descs, d_pages, d_seg_owner, n_segs, d_scans, buf, d_tabs);
-    // two rounds: a segment entered at the wrong place usually still leaves at the right one (its walk
-    // falls into step inside it), so the first round sets most entries right and the second the few
-    // whose predecessor's exit was itself wrong at first
+    // A segment entered at the wrong place usually still leaves at the right one (its walk falls into
+    // step inside it), so the first round sets most entries right; a second one sets right the few whose
+    // predecessor's exit was itself wrong at first.  What is left the link pass repairs itself, a page's
+    // repairs one after the other: with streams of narrow values (level streams, booleans) that is one
+    // repair for a page at most and the second round is not worth its launch (64 definition-level streams
+    // of 1 M: 0.26 -> 0.24 ms without it); with 12-bit keys it is (0.35 -> 0.40 ms without it).
     hipLaunchKernelGGL(lseg_fix_kernel, gs, dim3(kWG), 0, s, d_descs, d_pages, d_seg_owner, n_segs, d_scans, d_scans + n_segs,
                        buf, d_tabs);
-    hipLaunchKernelGGL(lseg_fix_kernel, gs, dim3(kWG), 0, s, d_descs, d_pages, d_seg_owner, n_segs, d_scans + n_segs, d_scans,
-                       buf, d_tabs);
-    hipLaunchKernelGGL(lseg_link_kernel, gp, dim3(kWG), 0, s, d_descs, d_pages, n_pages, d_scans, d_recs, buf, d_tabs);
+    HsegScan *fixed = d_scans + n_segs;
+    if (fix_rounds > 1) {
+        hipLaunchKernelGGL(lseg_fix_kernel, gs, dim3(kWG), 0, s, d_descs, d_pages, d_seg_owner, n_segs, d_scans + n_segs,
+                           d_scans, buf, d_tabs);
+        fixed = d_scans;
+    }
+    hipLaunchKernelGGL(lseg_link_kernel, gp, dim3(kWG), 0, s, d_descs, d_pages, n_pages, fixed, d_recs, buf, d_tabs);
     if (dict_lds_bytes != 0u) {
         const size_t lds = hs_lds_fixed(kHsWavesDict) + dict_lds_bytes;
         if (lds > 65536) {
